@@ -1,0 +1,379 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+A restatement of the reference's parse -> correct -> render-matrix algorithms
+used to check the HIP path.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product package never
+does.
+
+Integer stages (tokenise, frame, group, baseline, correct, pivot sums) are the
+sequential C restatement in slam_oracle.c, reached through ctypes.  Float
+stages (mean, Gaussian kernel, NaN-aware blur, edges, normalise, colour, raster
+index maps) are NumPy float64.
+
+Pinned against the reference's own functions (imported in the build container
+by tests/golden/make_golden.py and by tests that skip when /root/reference is
+absent), the committed debugDoc/*.xlsx outputs and the reference's embedded
+unit tests.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_SRC = os.path.join(_HERE, "slam_oracle.c")
+
+CYCLE = 61000      # bs_beam_correction.py:23
+TOL = 500          # bs_beam_correction.py:24
+MOD_BASE = 64      # bs_beam_correction.py:25
+
+
+def build(force: bool = False) -> str:
+    """Compile slam_oracle.c with gcc (also done by `make -C oracle`)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(
+            ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", _SO, _SRC, "-lm"]
+        )
+    return _SO
+
+
+_lib = None
+
+
+def _L():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        lib = ctypes.CDLL(_SO)
+        i64 = ctypes.c_int64
+        p = ctypes.c_void_p
+        lib.orc_read_bytes.restype = i64
+        lib.orc_read_bytes.argtypes = [p, i64, p]
+        lib.orc_parse_groups.restype = None
+        lib.orc_parse_groups.argtypes = [p, i64, p, p, p, p, p, p, p, p, p, i64]
+        lib.orc_detect_groups.restype = i64
+        lib.orc_detect_groups.argtypes = [p, i64, p]
+        lib.orc_identify_baselines.restype = i64
+        lib.orc_identify_baselines.argtypes = [p, p, p, p, p, i64, p, p, p]
+        lib.orc_filter_corrected.restype = i64
+        lib.orc_filter_corrected.argtypes = [p, p, p, p, p, i64, i64, i64, i64, p, p, p, p, p, p]
+        lib.orc_correct_inplace.restype = None
+        lib.orc_correct_inplace.argtypes = [p, p, p, p, p, i64, i64, i64, i64, p, p]
+        lib.orc_pivot.restype = None
+        lib.orc_pivot.argtypes = [p, p, p, i64, p, ctypes.c_int, p, p]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i64(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------
+# a1  serial_hex_to_excel_v3._read_bytes  (:18-36)
+# ---------------------------------------------------------------------------
+def read_bytes(text: bytes) -> np.ndarray:
+    """Raw file bytes -> uint8 array of the kept hex tokens."""
+    buf = np.frombuffer(bytes(text), dtype=np.uint8)
+    out = np.empty(len(buf) // 2 + 2, dtype=np.uint8)
+    n = _L().orc_read_bytes(_ptr(buf) if len(buf) else None, len(buf), _ptr(out))
+    return out[:n].copy()
+
+
+def read_bytes_py(text: bytes) -> np.ndarray:
+    """The same through CPython's own decoder/split (small inputs; cross-check of the C tokenizer)."""
+    out = []
+    for t in bytes(text).decode("utf-8", errors="ignore").split():
+        s = t
+        if len(s) == 4 and s[:2] == "0x":
+            s = s[2:]
+        if len(s) == 2 and all(c in "0123456789abcdefABCDEF" for c in s):
+            out.append(int(s, 16))
+    return np.array(out, dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# a2  serial_hex_to_excel_v3._parse_groups  (:41-103)
+# ---------------------------------------------------------------------------
+def parse_groups(data, want_rejects: bool = False):
+    """bytes -> dict(flag, ue, bs, rss, clk arrays), valid, discarded[, reject_pos, reject_reason]."""
+    b = np.ascontiguousarray(np.asarray(data, dtype=np.uint8))
+    n = len(b)
+    cap = n // 11 + 1
+    flag = np.empty(cap, np.uint8)
+    ue = np.empty(cap, np.uint8)
+    bs = np.empty(cap, np.uint8)
+    rss = np.empty(cap, np.uint32)
+    clk = np.empty(cap, np.uint32)
+    nv = ctypes.c_int64(0)
+    nd = ctypes.c_int64(0)
+    rp = np.empty(n + 1 if want_rejects else 1, np.int64)
+    rr = np.empty(n + 1 if want_rejects else 1, np.uint8)
+    _L().orc_parse_groups(
+        _ptr(b) if n else None, n, _ptr(flag), _ptr(ue), _ptr(bs), _ptr(rss), _ptr(clk),
+        ctypes.byref(nv), ctypes.byref(nd),
+        _ptr(rp) if want_rejects else None, _ptr(rr) if want_rejects else None,
+        len(rp) if want_rejects else 0,
+    )
+    v, d = nv.value, nd.value
+    rows = dict(flag=flag[:v].copy(), ue=ue[:v].copy(), bs=bs[:v].copy(),
+                rss=rss[:v].copy(), clk=clk[:v].copy())
+    if want_rejects:
+        return rows, v, d, rp[:d].copy(), rr[:d].copy()
+    return rows, v, d
+
+
+def parse_groups_py(data: Sequence[int]):
+    """Literal pure-Python loop of the same scan (tiny inputs; cross-check of the C scan)."""
+    b = [int(x) for x in data]
+    n = len(b)
+    rows: List[Tuple[int, int, int, int, int]] = []
+    disc = 0
+    i = 0
+    while i < n:
+        f = b[i]
+        if f not in (0xCC, 0x33):
+            i += 1
+            continue
+        if i + 11 > n:
+            disc += 1
+            break
+        g = b[i + 1:i + 11]
+        tags = [(x >> 6) & 3 for x in g]
+        if tags != [0, 3, 1, 1, 1, 1, 1, 2, 2, 2]:
+            disc += 1
+            i += 1
+            continue
+        clk = sum((g[2 + j] & 63) << (6 * j) for j in range(5))
+        rss = sum((g[7 + j] & 63) << (6 * j) for j in range(3))
+        rows.append((1 if f == 0xCC else 0, g[0] & 63, g[1] & 63, rss, clk))
+        i += 11
+    return rows, len(rows), disc
+
+
+# ---------------------------------------------------------------------------
+# a4-a6  bs_beam_correction
+# ---------------------------------------------------------------------------
+def detect_groups(ue) -> np.ndarray:
+    """bs_beam_correction._detect_groups (:43-47)."""
+    u = _i64(ue)
+    gid = np.empty(len(u), np.int64)
+    _L().orc_detect_groups(_ptr(u), len(u), _ptr(gid))
+    return gid
+
+
+def identify_baselines(flag, ue, bs, rss, clk):
+    """All groups' baselines in order: (clk_b, bs_b, gid) arrays.  _identify_baselines (:50-61)."""
+    f, u, b, r, c = map(_i64, (flag, ue, bs, rss, clk))
+    n = len(f)
+    oc = np.empty(n + 1, np.int64)
+    ob = np.empty(n + 1, np.int64)
+    og = np.empty(n + 1, np.int64)
+    k = _L().orc_identify_baselines(_ptr(f), _ptr(u), _ptr(b), _ptr(r), _ptr(c), n,
+                                    _ptr(oc), _ptr(ob), _ptr(og))
+    return oc[:k].copy(), ob[:k].copy(), og[:k].copy()
+
+
+def filter_corrected(flag, ue, bs, rss, clk, cycle=CYCLE, tol=TOL, mod_base=MOD_BASE):
+    """process_excel_filtered's data path (:186-198 + :140-178): kept rows (ue, bs', rss, clk), n_groups, n_baselines."""
+    f, u, b, r, c = map(_i64, (flag, ue, bs, rss, clk))
+    n = len(f)
+    ou, ob, orr, oc = (np.empty(n + 1, np.int64) for _ in range(4))
+    ng = ctypes.c_int64(0)
+    nb = ctypes.c_int64(0)
+    k = _L().orc_filter_corrected(_ptr(f), _ptr(u), _ptr(b), _ptr(r), _ptr(c), n,
+                                  int(cycle), int(tol), int(mod_base),
+                                  _ptr(ou), _ptr(ob), _ptr(orr), _ptr(oc),
+                                  ctypes.byref(ng), ctypes.byref(nb))
+    return dict(ue=ou[:k].copy(), bs=ob[:k].copy(), rss=orr[:k].copy(), clk=oc[:k].copy()), ng.value, nb.value
+
+
+def correct_inplace(flag, ue, bs, rss, clk, cycle=CYCLE, tol=TOL, mod_base=MOD_BASE):
+    """process_excel's data path (_correct_group :79-116 over all groups): corrected_bs per row, was_corrected mask."""
+    f, u, b, r, c = map(_i64, (flag, ue, bs, rss, clk))
+    n = len(f)
+    out = np.empty(n, np.int64)
+    wc = np.empty(n, np.uint8)
+    _L().orc_correct_inplace(_ptr(f), _ptr(u), _ptr(b), _ptr(r), _ptr(c), n,
+                             int(cycle), int(tol), int(mod_base), _ptr(out), _ptr(wc))
+    return out, wc.astype(bool)
+
+
+# ---------------------------------------------------------------------------
+# a8-a10  mapping table, map_angles, compute_rssi_matrix
+# ---------------------------------------------------------------------------
+def axis_from_mapping(mapping: Dict[int, float]) -> Tuple[np.ndarray, np.ndarray]:
+    """BeamID->angle dict (ids 0..63, excel_heatmap_v3.py:246-247) -> (beam_to_axis int8[64], sorted distinct angles)."""
+    angles = sorted({float(a) for k, a in mapping.items() if 0 <= int(k) <= 63 and not math.isnan(float(a))})
+    pos = {a: i for i, a in enumerate(angles)}
+    b2a = np.full(64, -1, np.int8)
+    for k, a in mapping.items():
+        if 0 <= int(k) <= 63 and not math.isnan(float(a)):
+            b2a[int(k)] = pos[float(a)]
+    return b2a, np.array(angles, np.float64)
+
+
+def pivot_mean(ue, bs, rss, mapping: Dict[int, float]):
+    """map_angles (:264-280) + compute_rssi_matrix (:286-314).
+
+    Returns (matrix f64 [n_aod, n_aoa] with NaN for empty cells, aod_list, aoa_list,
+    sum int64 [n_axis,n_axis], cnt int64 [n_axis,n_axis]).  Axes hold only angles that occur.
+    """
+    b2a, angles = axis_from_mapping(mapping)
+    n_axis = len(angles)
+    u, b, r = map(_i64, (ue, bs, rss))
+    s = np.zeros((n_axis, n_axis), np.int64)
+    c = np.zeros((n_axis, n_axis), np.int64)
+    if n_axis:
+        _L().orc_pivot(_ptr(u), _ptr(b), _ptr(r), len(u), _ptr(b2a), n_axis, _ptr(s), _ptr(c))
+    rows = np.flatnonzero(c.sum(axis=1) > 0)
+    cols = np.flatnonzero(c.sum(axis=0) > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        full = np.where(c > 0, s.astype(np.float64) / c.astype(np.float64), np.nan)
+    mat = full[np.ix_(rows, cols)]
+    return mat, angles[rows].tolist(), angles[cols].tolist(), s, c
+
+
+# ---------------------------------------------------------------------------
+# a11-a12  gaussian_kernel (:320-333), gaussian_blur_nan_aware (:336-368)
+# ---------------------------------------------------------------------------
+def gaussian_kernel(sigma: float) -> np.ndarray:
+    if sigma <= 0:
+        return np.array([[1.0]], dtype=np.float64)
+    size = int(max(3, math.ceil(6 * sigma)))
+    if size % 2 == 0:
+        size += 1
+    c = size // 2
+    ax = np.arange(-c, c + 1, dtype=np.int64)
+    k = np.exp(-(ax[None, :] * ax[None, :] + ax[:, None] * ax[:, None]) / (2.0 * sigma * sigma))
+    return (k / k.sum()).astype(np.float64)
+
+
+def blur_nan_aware(data: np.ndarray, sigma: float) -> np.ndarray:
+    """Normalised convolution with edge padding; NaN where the weight sum is <= 1e-12."""
+    data = np.asarray(data, dtype=np.float64)
+    if sigma <= 0:
+        return data
+    k = gaussian_kernel(sigma)
+    kh, kw = k.shape
+    ph, pw = kh // 2, kw // 2
+    mask = np.isfinite(data).astype(np.float64)
+    filled = np.where(np.isfinite(data), data, 0.0)
+    pd_ = np.pad(filled, ((ph, ph), (pw, pw)), mode="edge")
+    pm = np.pad(mask, ((ph, ph), (pw, pw)), mode="edge")
+    H, W = data.shape
+    num = np.zeros((H, W), np.float64)
+    den = np.zeros((H, W), np.float64)
+    # plain row-major accumulation order over the kernel taps
+    for a in range(kh):
+        for b in range(kw):
+            w = k[a, b] * pm[a:a + H, b:b + W]
+            num += pd_[a:a + H, b:b + W] * w
+            den += w
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(den > 1e-12, num / den, np.nan)
+
+
+# ---------------------------------------------------------------------------
+# a13  generate_heatmap's data path (:396-456): edges, normalise, colour
+# ---------------------------------------------------------------------------
+def edges(vals: Sequence[float]) -> np.ndarray:
+    """_edges (:430-440): interior midpoints, outer edges half a step out; a single value gives +-0.5."""
+    v = np.asarray(vals, dtype=np.float64)
+    if len(v) == 1:
+        return np.array([v[0] - 0.5, v[0] + 0.5], dtype=np.float64)
+    e = np.empty(len(v) + 1, np.float64)
+    e[1:-1] = (v[:-1] + v[1:]) / 2.0
+    e[0] = v[0] - (v[1] - v[0]) / 2.0
+    e[-1] = v[-1] + (v[-1] - v[-2]) / 2.0
+    return e
+
+
+def normalise(mat: np.ndarray, use_log: bool, vmin: Optional[float], vmax: Optional[float]):
+    """Returns (norm in [0,1] or NaN, vmin_used, vmax_used) as the figure's colour scale does.
+
+    Linear (:420-423): Normalize autoscaled to the finite min/max.
+    Log (:409-419): shifted = mat - min + 1e-6, LogNorm between the (shifted) limits.
+    """
+    mat = np.asarray(mat, np.float64)
+    fin = np.isfinite(mat)
+    if not fin.any():
+        raise ValueError("matrix is all NaN")
+    if use_log:
+        mn = mat[fin].min()
+        sh = mat - mn + 1e-6
+        lo = (vmin - mn + 1e-6) if vmin is not None else sh[fin].min()
+        hi = (vmax - mn + 1e-6) if vmax is not None else sh[fin].max()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = np.log10(sh)
+        tlo, thi = math.log10(lo), math.log10(hi)
+        nrm = (t - tlo) / (thi - tlo) if thi != tlo else np.zeros_like(t)
+        return np.where(fin, nrm, np.nan), float(lo), float(hi)
+    lo = float(vmin) if vmin is not None else float(mat[fin].min())
+    hi = float(vmax) if vmax is not None else float(mat[fin].max())
+    if hi == lo:
+        nrm = np.zeros_like(mat)
+    else:
+        nrm = (mat - lo) / (hi - lo)
+    return np.where(fin, nrm, np.nan), lo, hi
+
+
+def colour_cells(nrm: np.ndarray, lut: np.ndarray) -> np.ndarray:
+    """norm -> RGBA8 per cell: LUT[clip(floor(norm*256), 0, 255)], NaN -> transparent (0,0,0,0).
+
+    lut is uint8 [256, 3]: the colormap's 256 colours as the saved PNG shows them, round(c*255).
+    """
+    h, w = nrm.shape
+    out = np.zeros((h, w, 4), np.uint8)
+    fin = np.isfinite(nrm)
+    x = np.where(fin, nrm, 0.0) * 256.0
+    idx = np.clip(np.floor(x), 0, 255).astype(np.int64)
+    out[..., :3] = lut[idx]
+    out[..., 3] = 255
+    out[~fin] = 0
+    return out
+
+
+def raster_index_maps(x_edges: np.ndarray, y_edges: np.ndarray, W: int, H: int):
+    """Data-only tile geometry: pixel (px, py) -> (col, row) cell indices.
+
+    The tile spans [x_edges[0], x_edges[-1]] x [y_edges[0], y_edges[-1]]; pixel
+    centres are sampled; py = 0 is the top (largest AoD), like the figure's axes.
+    """
+    xe = np.asarray(x_edges, np.float64)
+    ye = np.asarray(y_edges, np.float64)
+    sx = (xe[-1] - xe[0]) / np.float64(W)
+    sy = (ye[-1] - ye[0]) / np.float64(H)
+    X = xe[0] + (np.arange(W, dtype=np.float64) + 0.5) * sx
+    Y = ye[-1] - (np.arange(H, dtype=np.float64) + 0.5) * sy
+    col = np.clip(np.searchsorted(xe, X, side="right") - 1, 0, len(xe) - 2)
+    row = np.clip(np.searchsorted(ye, Y, side="right") - 1, 0, len(ye) - 2)
+    return col.astype(np.int32), row.astype(np.int32)
+
+
+def raster(cells_rgba: np.ndarray, x_edges, y_edges, W: int, H: int) -> np.ndarray:
+    col, row = raster_index_maps(x_edges, y_edges, W, H)
+    return cells_rgba[row[:, None], col[None, :]]
+
+
+def render(matrix, aod_list, aoa_list, lut, use_log=False, vmin=None, vmax=None,
+           blur_sigma=1.0, W=1024, H=1024):
+    """generate_heatmap's data path end to end: blur -> scale -> cell colours -> tile."""
+    mat = np.array(matrix, dtype=np.float64, copy=True)
+    if blur_sigma and blur_sigma > 0:
+        mat = blur_nan_aware(mat, blur_sigma)
+    nrm, lo, hi = normalise(mat, use_log, vmin, vmax)
+    cells = colour_cells(nrm, lut)
+    tile = raster(cells, edges(aoa_list), edges(aod_list), W, H)
+    return dict(blurred=mat, norm=nrm, vmin=lo, vmax=hi, cells=cells, tile=tile)
