@@ -1,0 +1,200 @@
+/*
+ * slamhip.h -- C ABI of libslamhip.so, the MI355X (gfx950) implementation of the
+ * slam-process decode -> correct -> raster hot path.
+ *
+ * The reference (lull21/slam-process) has no native interface: its hot path is
+ * the module-level Python functions of serial_hex_to_excel_v3.py,
+ * bs_beam_correction.py and excel_heatmap_v3.py.  Each entry point below names
+ * the reference function(s) whose data path it replaces; the Python modules of
+ * the same names in slam-process_amd/ bind them through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SLAM_E_* code;
+ *     slam_last_error(ctx) gives the message of the last failure on that ctx;
+ *   - all buffers are caller-owned, sizes are explicit, nothing is retained
+ *     after return except the ctx's own device workspace;
+ *   - plain entry points take HOST pointers and are synchronous;
+ *     *_dev entry points take DEVICE pointers, enqueue on the ctx's stream and
+ *     return without synchronising (call slam_sync);
+ *   - a ctx is bound to one device and one stream and is not thread-safe.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK              0
+#define SLAM_E_INVALID      -1   /* bad argument (NULL pointer, size out of range) */
+#define SLAM_E_HIP          -2   /* a HIP runtime call failed */
+#define SLAM_E_CAPACITY     -3   /* an output buffer is too small; required size is reported */
+#define SLAM_E_EMPTY        -4   /* the stage produced no rows (the reference raises ValueError) */
+#define SLAM_E_ALLNAN       -5   /* matrix has no finite cell (excel_heatmap_v3.py:405-406) */
+#define SLAM_E_RANGE        -6   /* a value does not fit the device representation */
+
+typedef struct slam_ctx slam_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int slam_ctx_create(int device, slam_ctx **out);
+int slam_ctx_destroy(slam_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the ctx's own stream. */
+int slam_set_stream(slam_ctx *ctx, void *hip_stream);
+int slam_sync(slam_ctx *ctx);
+const char *slam_last_error(slam_ctx *ctx);
+const char *slam_version(void);
+
+/* ---- a1: hex text -> bytes ---------------------------------------------------------------
+ * Replaces _read_bytes (serial_hex_to_excel_v3.py:18-36, regex :16): UTF-8 decode with
+ * errors="ignore", split on Unicode whitespace, keep tokens of exactly two hex digits with an
+ * optional lowercase "0x".  bytes_out needs room for n_text/2 + 1 bytes at most. */
+int slam_hex_unpack(slam_ctx *ctx, const uint8_t *text, size_t n_text,
+                    uint8_t *bytes_out, size_t cap, size_t *n_bytes);
+
+/* ---- a2: bytes -> records ------------------------------------------------------------------
+ * Replaces _parse_groups (serial_hex_to_excel_v3.py:41-103): the resynchronising scan for
+ * 11-byte records FLAG UE BS CLK0..4 RSS0..2.  Outputs are struct-of-arrays in record order;
+ * cap >= n/11 + 1 always suffices.  n_valid / n_discarded are the reference's two counters. */
+int slam_parse_records(slam_ctx *ctx, const uint8_t *bytes, size_t n,
+                       uint8_t *flag, uint8_t *ue, uint8_t *bs, uint32_t *rss, uint32_t *clk,
+                       size_t cap, size_t *n_valid, size_t *n_discarded);
+
+/* a1+a2 fused: text straight to records (the text is never materialised as bytes when it has
+ * the capture format "XX XX XX ..." with an optional leading "« "). */
+int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text,
+                    uint8_t *flag, uint8_t *ue, uint8_t *bs, uint32_t *rss, uint32_t *clk,
+                    size_t cap, size_t *n_valid, size_t *n_discarded);
+
+/* ---- a4-a7: BS beam correction -----------------------------------------------------------------
+ * Replaces _detect_groups (:43-47), _identify_baselines (:50-61), _filter_group_corrected
+ * (:140-178) and _correct_group (:79-116) of bs_beam_correction.py, over a whole table as
+ * process_excel_filtered (:186-198) / process_excel (:125-134) drive them.
+ *
+ * Columns are int32 (|clk| < 2^30).  Any output pointer may be NULL.
+ *   out_*        kept rows in order (UE_Beam, corrected BS_Beam, RSS, CLK), capacity n
+ *   gid_out      group id per input row                                      [n]
+ *   corrected    per input row: the corrected BS where a candidate won, else -1   [n]
+ *   bl_clk/bl_bs/bl_gid  the baselines found, in order, capacity n/2 + 1
+ * If bl_in_n >= 0 the table is treated as ONE group whose baselines are the given
+ * bl_in_clk/bl_in_bs (the explicit `baselines` argument of the reference's per-group functions). */
+int slam_correct(slam_ctx *ctx,
+                 const int32_t *flag, const int32_t *ue, const int32_t *bs,
+                 const int32_t *rss, const int32_t *clk, size_t n,
+                 int32_t cycle, int32_t tol, int32_t mod_base,
+                 const int32_t *bl_in_clk, const int32_t *bl_in_bs, int64_t bl_in_n,
+                 int32_t *out_ue, int32_t *out_bs, int32_t *out_rss, int32_t *out_clk, size_t *n_kept,
+                 int32_t *gid_out, int32_t *corrected,
+                 int32_t *bl_clk, int32_t *bl_bs, int32_t *bl_gid, size_t *n_baselines,
+                 size_t *n_groups);
+
+/* ---- a9-a10: angle mapping + mean pivot ---------------------------------------------------------
+ * Replaces map_angles (excel_heatmap_v3.py:264-280) + compute_rssi_matrix (:286-314).
+ * beam_to_axis[64]: index of each beam's angle among the sorted distinct mapped angles, -1 if
+ * unmapped (rows using it are dropped); n_axis <= 64.  Rows with a beam outside 0..63 are dropped.
+ * sum/cnt: exact integer accumulators [n_axis*n_axis] (row = AoD axis of BS, col = AoA axis of UE).
+ * matrix: mean as f64, NaN where cnt == 0, same layout.  rss values must be in [0, 2^31). */
+int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const int32_t *rss, size_t n,
+                    const int8_t *beam_to_axis, int n_axis,
+                    int64_t *sum, int64_t *cnt, double *matrix);
+
+/* ---- a11-a12: NaN-aware Gaussian blur --------------------------------------------------------------
+ * Replaces gaussian_kernel (:320-333) + gaussian_blur_nan_aware (:336-368): normalised
+ * convolution, edge padding, NaN where the weight sum <= 1e-12.  h, w <= 256.  sigma <= 0 copies. */
+int slam_blur_nan(slam_ctx *ctx, const double *in, int h, int w, double sigma, double *out);
+
+/* ---- a13: colour scale + mesh raster --------------------------------------------------------------
+ * Replaces the data path of generate_heatmap (:396-456) after the blur: finite min/max,
+ * Normalize / shifted LogNorm, 256-entry colormap lookup, and the pcolormesh of flat cells with
+ * edges at midpoints (_edges :430-440), sampled into a data-only W x H RGBA tile (row 0 = largest
+ * AoD).  vmin/vmax: NaN = autoscale.  Outputs (any may be NULL): cells_rgba [h*w*4],
+ * tile_rgba [H*W*4], vmin_vmax_out[2] the limits used (after the log shift when use_log). */
+int slam_render(slam_ctx *ctx, const double *mat, int h, int w,
+                const double *aod, const double *aoa, int use_log, double vmin, double vmax,
+                const uint8_t *lut256x3, uint8_t *cells_rgba, uint8_t *tile_rgba, int W, int H,
+                double *vmin_vmax_out);
+
+/* ---- batched, device-resident pipeline (the benchmark path) ----------------------------------------
+ * F frames of hex text resident in device memory -> per frame: decoded records, corrected rows,
+ * mean matrix, blurred matrix, RGBA tile.  Everything stays on the device; nothing synchronises.
+ * All *_dev pointers are device pointers; optional outputs may be NULL. */
+typedef struct slam_batch {
+    /* inputs */
+    const uint8_t *text_dev;      /* all frames' text                                           */
+    const uint64_t *text_off_dev; /* [F] byte offset of each frame's text                        */
+    const uint32_t *text_len_dev; /* [F] text bytes of each frame                                */
+    uint32_t n_frames;            /* F                                                            */
+    uint32_t max_text_len;        /* max over frames of text_len (host-known upper bound)        */
+    uint32_t src_is_bytes;        /* 0: text_dev holds hex text in the capture format;            */
+                                  /* 1: it holds already-unpacked data bytes (slam_hex_unpack)    */
+    int32_t cycle, tol, mod_base; /* CYCLE, TOL, MOD_BASE (bs_beam_correction.py:23-25)          */
+    const int8_t *beam_to_axis_dev;   /* [64]                                                    */
+    const double *axis_angle_dev;     /* [n_axis] sorted distinct angles                         */
+    int32_t n_axis;
+    double blur_sigma;            /* --blur-sigma, default 1.0 (excel_heatmap_v3.py:601-603)      */
+    int32_t use_log;              /* --logscale                                                   */
+    double vmin, vmax;            /* NaN = autoscale                                              */
+    const uint8_t *lut_dev;       /* [256*3]                                                      */
+    int32_t tile_w, tile_h;
+    /* outputs; row arrays have row_cap entries per frame, frame f at offset f*row_cap */
+    uint32_t row_cap;             /* multiple of 16, >= max_text_len/33 + 2 (/11 for bytes)       */
+    uint8_t *flag_dev, *ue_dev, *bs_dev;        /* decoded records                               */
+    uint32_t *rss_dev, *clk_dev;
+    uint8_t *kept_ue_dev, *kept_bs_dev;         /* corrected rows                                */
+    uint32_t *kept_rss_dev, *kept_clk_dev;
+    uint32_t *stats_dev;          /* [F*SLAM_STAT_WORDS], see SLAM_STAT_*                         */
+    double *matrix_dev;           /* [F*n_axis*n_axis] mean, NaN = empty (full axis grid)         */
+    double *blurred_dev;          /* [F*n_axis*n_axis] blurred compact matrix, row stride n_aoa   */
+    uint8_t *tile_dev;            /* [F*tile_h*tile_w*4]                                          */
+} slam_batch;
+
+#define SLAM_STAT_WORDS      16
+#define SLAM_STAT_NBYTES      0   /* data bytes decoded from the text                            */
+#define SLAM_STAT_NOT_STRICT  1   /* 1 = text is not in the strict capture format: frame skipped  */
+#define SLAM_STAT_VALID       2   /* reference's `valid`                                          */
+#define SLAM_STAT_DISCARDED   3   /* reference's `discarded`                                      */
+#define SLAM_STAT_GROUPS      4
+#define SLAM_STAT_BASELINES   5
+#define SLAM_STAT_KEPT        6
+#define SLAM_STAT_N_AOD       7   /* rows of the compact matrix                                   */
+#define SLAM_STAT_N_AOA       8   /* cols of the compact matrix                                   */
+#define SLAM_STAT_ALLNAN      9   /* 1 = no finite cell, tile left transparent                    */
+#define SLAM_STAT_VMIN_LO    10   /* vmin/vmax used, as two u32 halves of an f64 each             */
+#define SLAM_STAT_VMIN_HI    11
+#define SLAM_STAT_VMAX_LO    12
+#define SLAM_STAT_VMAX_HI    13
+
+/* Replaces, per frame, the chain main() -> _read_bytes -> _parse_groups
+ * (serial_hex_to_excel_v3.py:153-154), process_excel_filtered's data path
+ * (bs_beam_correction.py:186-198) and process_excel_to_heatmap's data path
+ * (excel_heatmap_v3.py:519-545) without the xlsx hops between them.
+ * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones). */
+int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
+
+/* Bytes of ctx workspace slam_process_frames_dev needs for this batch shape (it grows the
+ * workspace itself on first use; callers that must not allocate later call this once up front). */
+int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch);
+
+/* Deterministic synthetic capture generator (device): frame `frame_index` of shape B rows x
+ * N records into text_dev (needs slam_synth_text_len(B, N) bytes).  Byte-identical to the
+ * NumPy generator slamhip.synth.make_frame_text. */
+size_t slam_synth_text_len(uint32_t B, uint32_t N);
+int slam_synth_frames_dev(slam_ctx *ctx, uint8_t *text_dev, uint64_t frame_stride,
+                          uint32_t first_frame, uint32_t n_frames, uint32_t B, uint32_t N, uint64_t seed);
+
+/* Device bandwidth probe used by the benchmark for the measured-copy ceiling: dst <- src, n bytes. */
+int slam_copy_probe_dev(slam_ctx *ctx, void *dst_dev, const void *src_dev, size_t n);
+
+/* Timing of the kernels a ctx launched since slam_timing_reset: per kernel name, launches and
+ * total milliseconds from HIP events recorded on the ctx's stream around each launch (only when
+ * enabled; off by default).  names_out receives up to cap entries of 32 chars. */
+int slam_timing_enable(slam_ctx *ctx, int on);
+int slam_timing_reset(slam_ctx *ctx);
+int slam_timing_read(slam_ctx *ctx, char *names_out, uint32_t *launches_out, float *ms_out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

@@ -210,6 +210,25 @@ def correct_inplace(flag, ue, bs, rss, clk, cycle=CYCLE, tol=TOL, mod_base=MOD_B
     return out, wc.astype(bool)
 
 
+def filter_group_py(rows, baselines, cycle=CYCLE, tol=TOL, mod_base=MOD_BASE):
+    """Literal loop of _filter_group_corrected (:140-178) for ONE group with explicit baselines (small inputs)."""
+    out = []
+    for flag, ue, bs, rss, clk in rows:
+        if int(flag) == 1 or not baselines:
+            continue
+        cands = []
+        for clk_b, bs_b in baselines:
+            d = int(clk) - int(clk_b)
+            k = int(round(d / cycle))
+            resid = abs(d - k * cycle)
+            if resid <= tol:
+                cands.append((resid, (int(bs_b) + k) % mod_base))
+        if cands:
+            cands.sort(key=lambda x: x[0])
+            out.append([int(ue), int(cands[0][1]), int(rss), int(clk)])
+    return out
+
+
 # ---------------------------------------------------------------------------
 # a8-a10  mapping table, map_angles, compute_rssi_matrix
 # ---------------------------------------------------------------------------
@@ -330,7 +349,7 @@ def normalise(mat: np.ndarray, use_log: bool, vmin: Optional[float], vmax: Optio
 
 
 def colour_cells(nrm: np.ndarray, lut: np.ndarray) -> np.ndarray:
-    """norm -> RGBA8 per cell: LUT[clip(floor(norm*256), 0, 255)], NaN -> transparent (0,0,0,0).
+    """norm -> RGBA8 per cell: LUT[clip(floor(norm*256), 0, 255)], NaN -> set_bad's (255,255,255,0) (:447).
 
     lut is uint8 [256, 3]: the colormap's 256 colours as the saved PNG shows them, round(c*255).
     """
@@ -341,7 +360,7 @@ def colour_cells(nrm: np.ndarray, lut: np.ndarray) -> np.ndarray:
     idx = np.clip(np.floor(x), 0, 255).astype(np.int64)
     out[..., :3] = lut[idx]
     out[..., 3] = 255
-    out[~fin] = 0
+    out[~fin] = (255, 255, 255, 0)
     return out
 
 

@@ -1,0 +1,667 @@
+// C-ABI entry points of libslamhip.so (declared in include/slamhip.h) and the context plumbing.
+
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "pipeline.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------
+int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+extern "C" const char *slam_version(void) { return "slamhip 0.1 (gfx950)"; }
+
+extern "C" int slam_ctx_create(int device, slam_ctx **out)
+{
+    if (!out) return SLAM_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SLAM_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return SLAM_E_HIP;
+    slam_ctx *c = new slam_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SLAM_E_HIP; }
+    c->stream = c->own_stream;
+    if (hipHostMalloc((void **)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+        hipStreamDestroy(c->own_stream);
+        delete c;
+        return SLAM_E_HIP;
+    }
+    *out = c;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ctx_destroy(slam_ctx *ctx)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->kern_dev) hipFree(ctx->kern_dev);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SLAM_OK;
+}
+
+extern "C" int slam_set_stream(slam_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SLAM_OK;
+}
+
+extern "C" int slam_sync(slam_ctx *ctx)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+extern "C" const char *slam_last_error(slam_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int slam_ws_reserve(slam_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_size) return SLAM_OK;
+    SLAM_HIP(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) SLAM_HIP(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_size = 0;
+    size_t want = bytes + bytes / 8 + (1 << 20);
+    hipError_t e = hipMalloc((void **)&ctx->ws, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc((void **)&ctx->ws, want);
+    }
+    if (e != hipSuccess) return slam_fail(ctx, SLAM_E_HIP, "hipMalloc of %zu workspace bytes failed: %s", want,
+                                          hipGetErrorString(e));
+    ctx->ws_size = want;
+    return SLAM_OK;
+}
+
+void slam_ws_reset(slam_ctx *ctx) { ctx->ws_used = 0; }
+
+void *slam_ws_take(slam_ctx *ctx, size_t bytes)
+{
+    size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->ws_used + need > ctx->ws_size) return nullptr;
+    void *p = ctx->ws + ctx->ws_used;
+    ctx->ws_used += need;
+    return p;
+}
+
+// Gaussian kernel cached on the device per ctx; re-uploaded only when sigma changes.
+static int get_kernel(slam_ctx *ctx, double sigma, double **kern, int *ks)
+{
+    constexpr int KMAX = 127;
+    if (!ctx->kern_dev) SLAM_HIP(ctx, hipMalloc((void **)&ctx->kern_dev, KMAX * KMAX * sizeof(double)));
+    if (ctx->kern_size == 0 || ctx->kern_sigma != sigma) {
+        std::vector<double> k;
+        int size = slam_gaussian_kernel_host(sigma, k);
+        if (size > KMAX) return slam_fail(ctx, SLAM_E_RANGE, "blur sigma %.3f needs a %d-tap kernel (max %d)", sigma, size, KMAX);
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SLAM_HIP(ctx, hipMemcpy(ctx->kern_dev, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->kern_sigma = sigma;
+        ctx->kern_size = size;
+    }
+    *kern = ctx->kern_dev;
+    *ks = ctx->kern_size;
+    return SLAM_OK;
+}
+
+// ---- timing ----------------------------------------------------------------------------------------------
+int slam_timer_begin(slam_ctx *ctx, const char *name)
+{
+    int slot = -1;
+    for (size_t i = 0; i < ctx->timers.size(); i++)
+        if (!strncmp(ctx->timers[i].name, name, 31)) { slot = (int)i; break; }
+    if (slot < 0) {
+        slam_timer_slot s;
+        memset(&s, 0, sizeof(s));
+        strncpy(s.name, name, 31);
+        ctx->timers.push_back(s);
+        slot = (int)ctx->timers.size() - 1;
+    }
+    slam_ctx::pending_ev p;
+    p.slot = slot;
+    for (hipEvent_t *e : {&p.a, &p.b}) {
+        if (!ctx->ev_pool.empty()) { *e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) return -1;
+    }
+    hipEventRecord(p.a, ctx->stream);
+    ctx->pending.push_back(p);
+    return (int)ctx->pending.size() - 1;
+}
+
+void slam_timer_end(slam_ctx *ctx, int token) { hipEventRecord(ctx->pending[token].b, ctx->stream); }
+
+static void timers_collect(slam_ctx *ctx)
+{
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->timers[p.slot].launches++;
+            ctx->timers[p.slot].ms += ms;
+        }
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int slam_timing_enable(slam_ctx *ctx, int on)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    if (!on) timers_collect(ctx);
+    ctx->timing = on != 0;
+    return SLAM_OK;
+}
+
+extern "C" int slam_timing_reset(slam_ctx *ctx)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    timers_collect(ctx);
+    ctx->timers.clear();
+    return SLAM_OK;
+}
+
+extern "C" int slam_timing_read(slam_ctx *ctx, char *names_out, uint32_t *launches_out, float *ms_out, int cap)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    timers_collect(ctx);
+    int n = (int)std::min<size_t>(ctx->timers.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; i++) {
+        if (names_out) memcpy(names_out + 32 * i, ctx->timers[i].name, 32);
+        if (launches_out) launches_out[i] = ctx->timers[i].launches;
+        if (ms_out) ms_out[i] = (float)ctx->timers[i].ms;
+    }
+    return (int)ctx->timers.size();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// helpers for the host-pointer entry points
+// ------------------------------------------------------------------------------------------------------
+#define REQUIRE_CTX(ctx)                                                                       \
+    do {                                                                                       \
+        if (!(ctx)) return SLAM_E_INVALID;                                                     \
+        if (hipSetDevice((ctx)->device) != hipSuccess) return slam_fail((ctx), SLAM_E_HIP, "hipSetDevice failed"); \
+    } while (0)
+
+static uint32_t round16(uint64_t v) { return (uint32_t)((v + 15) & ~uint64_t(15)); }
+
+static int h2d(slam_ctx *ctx, void *dst, const void *src, size_t n)
+{
+    if (n) SLAM_HIP(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx->stream));
+    return SLAM_OK;
+}
+static int d2h(slam_ctx *ctx, void *dst, const void *src, size_t n)
+{
+    if (n) SLAM_HIP(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx->stream));
+    return SLAM_OK;
+}
+
+// one frame on the device, decoded through the TEXT3 or RAW source; rows land in ws-carved arrays
+struct one_frame {
+    uint8_t *src;           // device copy of the input
+    uint64_t *off;
+    uint32_t *len;
+    uint32_t *stats;
+    rows_out rows;
+    frame_ws fws;
+    uint32_t nt_max;
+};
+
+static size_t one_frame_plan(ws_plan &p, size_t n_src, uint32_t row_cap, uint32_t nt_max, size_t off[16])
+{
+    off[0] = p.add(n_src + 32);
+    off[1] = p.add(8);
+    off[2] = p.add(4);
+    off[3] = p.add(SLAM_STAT_WORDS * 4);
+    off[4] = p.add(row_cap);
+    off[5] = p.add(row_cap);
+    off[6] = p.add(row_cap);
+    off[7] = p.add((size_t)row_cap * 4);
+    off[8] = p.add((size_t)row_cap * 4);
+    frame_ws::plan(p, 1, nt_max, off + 9);
+    return p.total;
+}
+
+static void one_frame_bind(one_frame &f, uint8_t *b, const size_t off[16], uint32_t row_cap, uint32_t nt_max)
+{
+    f.src = b + off[0];
+    f.off = (uint64_t *)(b + off[1]);
+    f.len = (uint32_t *)(b + off[2]);
+    f.stats = (uint32_t *)(b + off[3]);
+    f.rows.flag = b + off[4];
+    f.rows.ue = b + off[5];
+    f.rows.bs = b + off[6];
+    f.rows.rss = (uint32_t *)(b + off[7]);
+    f.rows.clk = (uint32_t *)(b + off[8]);
+    f.rows.row_cap = row_cap;
+    f.fws.summ = (uint32_t *)(b + off[9]);
+    f.fws.tile_entry = b + off[10];
+    f.fws.tile_off = (uint32_t *)(b + off[11]);
+    f.nt_max = nt_max;
+}
+
+static int set_one_frame_desc(slam_ctx *ctx, one_frame &f, uint32_t len)
+{
+    uint64_t *po = (uint64_t *)ctx->pinned;
+    uint32_t *pl = ctx->pinned + 4;
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));         // pinned words are reused between calls
+    *po = 0;
+    *pl = len;
+    SLAM_TRY(h2d(ctx, f.off, po, 8));
+    SLAM_TRY(h2d(ctx, f.len, pl, 4));
+    SLAM_HIP(ctx, hipMemsetAsync(f.stats, 0, SLAM_STAT_WORDS * 4, ctx->stream));
+    return SLAM_OK;
+}
+
+static int read_stats(slam_ctx *ctx, const uint32_t *stats_dev, uint32_t out[SLAM_STAT_WORDS])
+{
+    SLAM_TRY(d2h(ctx, ctx->pinned + 16, stats_dev, SLAM_STAT_WORDS * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned + 16, SLAM_STAT_WORDS * 4);
+    return SLAM_OK;
+}
+
+static int download_rows(slam_ctx *ctx, const rows_out &r, size_t n, uint8_t *flag, uint8_t *ue, uint8_t *bs,
+                         uint32_t *rss, uint32_t *clk)
+{
+    if (flag) SLAM_TRY(d2h(ctx, flag, r.flag, n));
+    if (ue) SLAM_TRY(d2h(ctx, ue, r.ue, n));
+    if (bs) SLAM_TRY(d2h(ctx, bs, r.bs, n));
+    if (rss) SLAM_TRY(d2h(ctx, rss, r.rss, n * 4));
+    if (clk) SLAM_TRY(d2h(ctx, clk, r.clk, n * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a1: hex text -> bytes
+// ------------------------------------------------------------------------------------------------------
+extern "C" int slam_hex_unpack(slam_ctx *ctx, const uint8_t *text, size_t n_text, uint8_t *bytes_out, size_t cap,
+                               size_t *n_bytes)
+{
+    REQUIRE_CTX(ctx);
+    if ((!text && n_text) || !n_bytes) return slam_fail(ctx, SLAM_E_INVALID, "slam_hex_unpack: null argument");
+    if (n_text > 0xFFFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "text larger than 4 GiB");
+    *n_bytes = 0;
+    if (n_text == 0) return SLAM_OK;
+    ws_plan p;
+    size_t o_text = p.add(n_text + 32), o_out = p.add(n_text / 2 + 32), o_cnt = p.add(4),
+           o_tok = p.add(tokenize_ws_bytes(n_text));
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    SLAM_TRY(h2d(ctx, b + o_text, text, n_text));
+    SLAM_TRY(tokenize_general(ctx, b + o_text, n_text, b + o_out, (uint32_t *)(b + o_cnt), b + o_tok));
+    SLAM_TRY(d2h(ctx, ctx->pinned, b + o_cnt, 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t n = ctx->pinned[0];
+    *n_bytes = n;
+    if (n > cap || (n && !bytes_out))
+        return slam_fail(ctx, SLAM_E_CAPACITY, "slam_hex_unpack: need room for %zu bytes, have %zu", n, cap);
+    SLAM_TRY(d2h(ctx, bytes_out, b + o_out, n));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a2: bytes -> records, and a1+a2 fused
+// ------------------------------------------------------------------------------------------------------
+static int parse_common(slam_ctx *ctx, int mode, const uint8_t *src, size_t n_src, uint8_t *flag, uint8_t *ue,
+                        uint8_t *bs, uint32_t *rss, uint32_t *clk, size_t cap, size_t *n_valid, size_t *n_disc)
+{
+    if ((!src && n_src) || !n_valid || !n_disc) return slam_fail(ctx, SLAM_E_INVALID, "parse: null argument");
+    if (n_src > 0xFFFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "input larger than 4 GiB");
+    *n_valid = 0;
+    *n_disc = 0;
+    if (n_src == 0) return SLAM_OK;
+    const uint64_t nb_max = mode == SRC_TEXT3 ? (n_src + 1) / 3 : n_src;
+    const uint32_t row_cap = round16(nb_max / 11 + 16);
+    const uint32_t nt_max = frame_tiles_for(mode, (uint32_t)n_src);
+    ws_plan p;
+    size_t off[16];
+    one_frame_plan(p, n_src, row_cap, nt_max, off);
+    // room for the general tokenizer's output and scratch when the text is not in the strict format
+    size_t o_gen = 0, o_gcnt = 0, o_gtok = 0;
+    if (mode == SRC_TEXT3) {
+        o_gen = p.add(n_src / 2 + 32);
+        o_gcnt = p.add(4);
+        o_gtok = p.add(tokenize_ws_bytes(n_src));
+    }
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    one_frame fr;
+    one_frame_bind(fr, ctx->ws, off, row_cap, nt_max);
+    SLAM_TRY(h2d(ctx, fr.src, src, n_src));
+    SLAM_TRY(set_one_frame_desc(ctx, fr, (uint32_t)n_src));
+    frame_src fs{fr.src, fr.off, fr.len};
+    SLAM_TRY(frame_decode(ctx, mode, fs, 1, (uint32_t)n_src, fr.fws, nt_max, fr.rows, fr.stats));
+    uint32_t st[SLAM_STAT_WORDS];
+    SLAM_TRY(read_stats(ctx, fr.stats, st));
+    if (mode == SRC_TEXT3 && st[SLAM_STAT_NOT_STRICT]) {
+        // free-form text: exact tokenizer, then the same framing on the byte stream
+        uint8_t *gen = ctx->ws + o_gen;
+        uint32_t *gcnt = (uint32_t *)(ctx->ws + o_gcnt);
+        SLAM_TRY(tokenize_general(ctx, fr.src, n_src, gen, gcnt, ctx->ws + o_gtok));
+        SLAM_TRY(d2h(ctx, ctx->pinned, gcnt, 4));
+        SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t nb = ctx->pinned[0];
+        SLAM_TRY(set_one_frame_desc(ctx, fr, nb));
+        frame_src gs{gen, fr.off, fr.len};
+        // the strict estimate (n/3 bytes) bounds the general count (n/2 at most -> tiles and rows still fit?)
+        const uint32_t nt_gen = frame_tiles_for(SRC_RAW, nb);
+        if (nt_gen > nt_max || (uint64_t)nb / 11 + 16 > row_cap)
+            return slam_fail(ctx, SLAM_E_CAPACITY, "free-form text decoded to more bytes than planned");
+        SLAM_TRY(frame_decode(ctx, SRC_RAW, gs, 1, nb, fr.fws, nt_max, fr.rows, fr.stats));
+        SLAM_TRY(read_stats(ctx, fr.stats, st));
+    }
+    *n_valid = st[SLAM_STAT_VALID];
+    *n_disc = st[SLAM_STAT_DISCARDED];
+    if (*n_valid > cap)
+        return slam_fail(ctx, SLAM_E_CAPACITY, "parse: need room for %zu records, have %zu", *n_valid, cap);
+    return download_rows(ctx, fr.rows, *n_valid, flag, ue, bs, rss, clk);
+}
+
+extern "C" int slam_parse_records(slam_ctx *ctx, const uint8_t *bytes, size_t n, uint8_t *flag, uint8_t *ue,
+                                  uint8_t *bs, uint32_t *rss, uint32_t *clk, size_t cap, size_t *n_valid,
+                                  size_t *n_discarded)
+{
+    REQUIRE_CTX(ctx);
+    return parse_common(ctx, SRC_RAW, bytes, n, flag, ue, bs, rss, clk, cap, n_valid, n_discarded);
+}
+
+extern "C" int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text, uint8_t *flag, uint8_t *ue,
+                               uint8_t *bs, uint32_t *rss, uint32_t *clk, size_t cap, size_t *n_valid,
+                               size_t *n_discarded)
+{
+    REQUIRE_CTX(ctx);
+    return parse_common(ctx, SRC_TEXT3, text, n_text, flag, ue, bs, rss, clk, cap, n_valid, n_discarded);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a4-a7: correction on int32 columns
+// ------------------------------------------------------------------------------------------------------
+extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *ue, const int32_t *bs,
+                            const int32_t *rss, const int32_t *clk, size_t n, int32_t cycle, int32_t tol,
+                            int32_t mod_base, const int32_t *bl_in_clk, const int32_t *bl_in_bs, int64_t bl_in_n,
+                            int32_t *out_ue, int32_t *out_bs, int32_t *out_rss, int32_t *out_clk, size_t *n_kept,
+                            int32_t *gid_out, int32_t *corrected, int32_t *bl_clk, int32_t *bl_bs, int32_t *bl_gid,
+                            size_t *n_baselines, size_t *n_groups)
+{
+    REQUIRE_CTX(ctx);
+    if (n_kept) *n_kept = 0;
+    if (n_baselines) *n_baselines = 0;
+    if (n_groups) *n_groups = 0;
+    if (n == 0) return SLAM_OK;
+    if (!flag || !ue || !bs || !rss || !clk) return slam_fail(ctx, SLAM_E_INVALID, "slam_correct: null column");
+    if (n > 0x7FFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "too many rows");
+    if (cycle <= 0 || cycle > (1 << 30) || mod_base <= 0)
+        return slam_fail(ctx, SLAM_E_INVALID, "cycle must be in 1..2^30 and mod_base positive");
+    const bool explicit_bl = bl_in_n >= 0;
+    if (explicit_bl && bl_in_n > 0 && (!bl_in_clk || !bl_in_bs))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_correct: null baseline arrays");
+    for (size_t i = 0; i < n; i++)
+        if (clk[i] <= -(1 << 30) || clk[i] >= (1 << 30))
+            return slam_fail(ctx, SLAM_E_RANGE, "clk[%zu] = %d is outside (-2^30, 2^30)", i, clk[i]);
+    for (int64_t i = 0; explicit_bl && i < bl_in_n; i++)
+        if (bl_in_clk[i] <= -(1 << 30) || bl_in_clk[i] >= (1 << 30))
+            return slam_fail(ctx, SLAM_E_RANGE, "baseline clk %d is outside (-2^30, 2^30)", bl_in_clk[i]);
+
+    const uint32_t row_cap = round16(n + 16);
+    const uint32_t bl_cap = std::max<uint32_t>(correct_ws::default_bl_cap(row_cap),
+                                               explicit_bl ? (uint32_t)bl_in_n + 16 : 0);
+    ws_plan p;
+    size_t oc[5], ok[4], ostat = p.add(SLAM_STAT_WORDS * 4), ogid = p.add((size_t)row_cap * 4), cw[16];
+    for (int i = 0; i < 5; i++) oc[i] = p.add((size_t)row_cap * 4);
+    for (int i = 0; i < 4; i++) ok[i] = p.add((size_t)row_cap * 4);
+    correct_ws::plan(p, 1, row_cap, bl_cap, cw);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    correct_ws ws;
+    ws.bind(b, cw, bl_cap);
+    uint32_t *stats = (uint32_t *)(b + ostat);
+    const int32_t *cols[5] = {flag, ue, bs, rss, clk};
+    for (int i = 0; i < 5; i++) SLAM_TRY(h2d(ctx, b + oc[i], cols[i], n * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(ctx->pinned, 0, SLAM_STAT_WORDS * 4);
+    ctx->pinned[SLAM_STAT_VALID] = (uint32_t)n;
+    if (explicit_bl) ctx->pinned[SLAM_STAT_BASELINES] = (uint32_t)bl_in_n;
+    SLAM_TRY(h2d(ctx, stats, ctx->pinned, SLAM_STAT_WORDS * 4));
+    if (explicit_bl && bl_in_n) {
+        SLAM_TRY(h2d(ctx, ws.bl_clk, bl_in_clk, (size_t)bl_in_n * 4));
+        SLAM_TRY(h2d(ctx, ws.bl_bs, bl_in_bs, (size_t)bl_in_n * 4));
+    }
+    rows_in_t<int32_t, int32_t> in{(int32_t *)(b + oc[0]), (int32_t *)(b + oc[1]), (int32_t *)(b + oc[2]),
+                                   (int32_t *)(b + oc[3]), (int32_t *)(b + oc[4]), row_cap};
+    kept_out_t<int32_t, int32_t> out{(int32_t *)(b + ok[0]), (int32_t *)(b + ok[1]), (int32_t *)(b + ok[2]),
+                                     (int32_t *)(b + ok[3])};
+    correct_params prm{cycle, tol, mod_base, explicit_bl ? 1 : 0};
+    SLAM_TRY((correct_rows<int32_t, int32_t>(ctx, in, 1, ws, prm, out, gid_out ? (int32_t *)(b + ogid) : nullptr,
+                                             stats)));
+    uint32_t st[SLAM_STAT_WORDS];
+    SLAM_TRY(read_stats(ctx, stats, st));
+    const size_t k = st[SLAM_STAT_KEPT], nb = st[SLAM_STAT_BASELINES];
+    if (n_kept) *n_kept = k;
+    if (n_baselines) *n_baselines = nb;
+    if (n_groups) *n_groups = st[SLAM_STAT_GROUPS];
+    int32_t *outs[4] = {out_ue, out_bs, out_rss, out_clk};
+    for (int i = 0; i < 4; i++)
+        if (outs[i]) SLAM_TRY(d2h(ctx, outs[i], b + ok[i], k * 4));
+    if (gid_out) SLAM_TRY(d2h(ctx, gid_out, b + ogid, n * 4));
+    if (corrected) SLAM_TRY(d2h(ctx, corrected, ws.corr, n * 4));
+    if (bl_clk) SLAM_TRY(d2h(ctx, bl_clk, ws.bl_clk, nb * 4));
+    if (bl_bs) SLAM_TRY(d2h(ctx, bl_bs, ws.bl_bs, nb * 4));
+    if (bl_gid) SLAM_TRY(d2h(ctx, bl_gid, ws.bl_gid, nb * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a9-a10: pivot
+// ------------------------------------------------------------------------------------------------------
+extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const int32_t *rss, size_t n,
+                               const int8_t *beam_to_axis, int n_axis, int64_t *sum, int64_t *cnt, double *matrix)
+{
+    REQUIRE_CTX(ctx);
+    if (!beam_to_axis || n_axis < 1 || n_axis > 64) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: bad axis table");
+    if (n && (!ue || !bs || !rss)) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: null column");
+    if (n > 0x7FFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "too many rows");
+    const uint32_t row_cap = round16(n + 16);
+    const int cells = n_axis * n_axis;
+    ws_plan p;
+    size_t oc[3], ostat = p.add(SLAM_STAT_WORDS * 4), ob2a = p.add(64), omat = p.add(4096 * 8), ocnt64 = p.add(4096 * 8), rw[5];
+    for (int i = 0; i < 3; i++) oc[i] = p.add((size_t)row_cap * 4);
+    render_ws::plan(p, 1, 1, 1, rw);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    render_ws ws;
+    ws.bind(b, rw);
+    uint32_t *stats = (uint32_t *)(b + ostat);
+    const int32_t *cols[3] = {ue, bs, rss};
+    for (int i = 0; i < 3; i++) SLAM_TRY(h2d(ctx, b + oc[i], cols[i], n * 4));
+    SLAM_TRY(h2d(ctx, b + ob2a, beam_to_axis, 64));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(ctx->pinned, 0, SLAM_STAT_WORDS * 4);
+    ctx->pinned[SLAM_STAT_KEPT] = (uint32_t)n;
+    SLAM_TRY(h2d(ctx, stats, ctx->pinned, SLAM_STAT_WORDS * 4));
+    render_params rp{};
+    rp.beam_to_axis = (const int8_t *)(b + ob2a);
+    rp.n_axis = n_axis;
+    SLAM_TRY((pivot_accumulate<int32_t, int32_t>(ctx, (int32_t *)(b + oc[0]), (int32_t *)(b + oc[1]),
+                                                 (int32_t *)(b + oc[2]), row_cap, 1, stats, SLAM_STAT_KEPT, rp, ws)));
+    SLAM_TRY(mean_only(ctx, ws.sum, ws.cnt, cells, (double *)(b + omat)));
+    std::vector<uint32_t> c32(cells);
+    if (sum) SLAM_TRY(d2h(ctx, sum, ws.sum, (size_t)cells * 8));
+    SLAM_TRY(d2h(ctx, c32.data(), ws.cnt, (size_t)cells * 4));
+    if (matrix) SLAM_TRY(d2h(ctx, matrix, b + omat, (size_t)cells * 8));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt) for (int i = 0; i < cells; i++) cnt[i] = c32[i];
+    (void)ocnt64;
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a11-a12: blur
+// ------------------------------------------------------------------------------------------------------
+extern "C" int slam_blur_nan(slam_ctx *ctx, const double *in, int h, int w, double sigma, double *out)
+{
+    REQUIRE_CTX(ctx);
+    if (!in || !out || h < 1 || w < 1 || h > 4096 || w > 4096) return slam_fail(ctx, SLAM_E_INVALID, "slam_blur_nan: bad shape");
+    const size_t bytes = (size_t)h * w * 8;
+    if (sigma <= 0) { memmove(out, in, bytes); return SLAM_OK; }       // returns the input unchanged (:340-341)
+    ws_plan p;
+    size_t oi = p.add(bytes), oo = p.add(bytes);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    double *kern;
+    int ks;
+    SLAM_TRY(get_kernel(ctx, sigma, &kern, &ks));
+    SLAM_TRY(h2d(ctx, b + oi, in, bytes));
+    SLAM_TRY(blur_only(ctx, (double *)(b + oi), h, w, kern, ks, (double *)(b + oo)));
+    SLAM_TRY(d2h(ctx, out, b + oo, bytes));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// a13: colour scale + raster
+// ------------------------------------------------------------------------------------------------------
+extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa,
+                           int use_log, double vmin, double vmax, const uint8_t *lut256x3, uint8_t *cells_rgba,
+                           uint8_t *tile_rgba, int W, int H, double *vmin_vmax_out)
+{
+    REQUIRE_CTX(ctx);
+    if (!mat || !aod || !aoa || !lut256x3 || h < 1 || w < 1 || h > 64 || w > 64)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_render: matrix must be 1..64 x 1..64 with axis lists and a LUT");
+    if (tile_rgba && (W < 1 || H < 1 || W > 16384 || H > 16384)) return slam_fail(ctx, SLAM_E_INVALID, "slam_render: bad tile size");
+    if (!tile_rgba) { W = 1; H = 1; }
+    ws_plan p;
+    size_t om = p.add((size_t)h * w * 8), oa = p.add(64 * 8), ob = p.add(64 * 8), ol = p.add(768), oc = p.add(4096 * 4),
+           ocm = p.add((size_t)W * 2), orm = p.add((size_t)H * 2), ost = p.add(SLAM_STAT_WORDS * 4),
+           ot = p.add((size_t)W * H * 4);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    SLAM_TRY(h2d(ctx, b + om, mat, (size_t)h * w * 8));
+    SLAM_TRY(h2d(ctx, b + oa, aod, (size_t)h * 8));
+    SLAM_TRY(h2d(ctx, b + ob, aoa, (size_t)w * 8));
+    SLAM_TRY(h2d(ctx, b + ol, lut256x3, 768));
+    SLAM_HIP(ctx, hipMemsetAsync(b + ost, 0, SLAM_STAT_WORDS * 4, ctx->stream));
+    SLAM_TRY(render_only(ctx, (double *)(b + om), h, w, (double *)(b + oa), (double *)(b + ob), use_log, vmin, vmax,
+                         b + ol, b + oc, tile_rgba ? b + ot : nullptr, W, H, (int16_t *)(b + ocm), (int16_t *)(b + orm),
+                         (uint32_t *)(b + ost)));
+    uint32_t st[SLAM_STAT_WORDS];
+    SLAM_TRY(read_stats(ctx, (uint32_t *)(b + ost), st));
+    if (st[SLAM_STAT_ALLNAN]) return slam_fail(ctx, SLAM_E_ALLNAN, "matrix has no finite cell");
+    if (vmin_vmax_out) {
+        uint64_t lo = (uint64_t)st[SLAM_STAT_VMIN_LO] | ((uint64_t)st[SLAM_STAT_VMIN_HI] << 32);
+        uint64_t hi = (uint64_t)st[SLAM_STAT_VMAX_LO] | ((uint64_t)st[SLAM_STAT_VMAX_HI] << 32);
+        memcpy(&vmin_vmax_out[0], &lo, 8);
+        memcpy(&vmin_vmax_out[1], &hi, 8);
+    }
+    if (cells_rgba) SLAM_TRY(d2h(ctx, cells_rgba, b + oc, (size_t)h * w * 4));
+    if (tile_rgba) SLAM_TRY(d2h(ctx, tile_rgba, b + ot, (size_t)W * H * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batched device-resident pipeline
+// ------------------------------------------------------------------------------------------------------
+struct batch_plan {
+    size_t fw[3], cw[16], rw[5];
+    uint32_t nt_max, bl_cap;
+    size_t total;
+};
+
+static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
+{
+    if (!bt || !bt->text_dev || !bt->text_off_dev || !bt->text_len_dev || !bt->stats_dev)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: text, offsets, lengths and stats are required");
+    if (bt->row_cap % 16 || (uint64_t)bt->row_cap < ((uint64_t)bt->max_text_len + (bt->src_is_bytes ? 0 : 1)) /
+                                                         (bt->src_is_bytes ? 11 : 33) + 2)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: row_cap must be a multiple of 16 and >= max_text_len/33 + 2");
+    ws_plan p;
+    bp.nt_max = frame_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
+    bp.bl_cap = correct_ws::default_bl_cap(bt->row_cap);
+    frame_ws::plan(p, bt->n_frames, bp.nt_max, bp.fw);
+    correct_ws::plan(p, bt->n_frames, bt->row_cap, bp.bl_cap, bp.cw);
+    render_ws::plan(p, bt->n_frames, bt->tile_w, bt->tile_h, bp.rw);
+    bp.total = p.total;
+    return SLAM_OK;
+}
+
+extern "C" int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch)
+{
+    REQUIRE_CTX(ctx);
+    batch_plan bp;
+    SLAM_TRY(plan_batch(ctx, batch, bp));
+    double *kern;
+    int ks;
+    SLAM_TRY(get_kernel(ctx, batch->blur_sigma, &kern, &ks));
+    return slam_ws_reserve(ctx, bp.total);
+}
+
+extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
+{
+    REQUIRE_CTX(ctx);
+    batch_plan bp;
+    SLAM_TRY(plan_batch(ctx, bt, bp));
+    const uint32_t F = bt->n_frames;
+    if (F == 0) return SLAM_OK;
+    if ((stages & 1u) && (!bt->flag_dev || !bt->ue_dev || !bt->bs_dev || !bt->rss_dev || !bt->clk_dev))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays are required");
+    if ((stages & 2u) && (!bt->kept_ue_dev || !bt->kept_bs_dev || !bt->kept_rss_dev || !bt->kept_clk_dev))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: corrected-row arrays are required");
+    if ((stages & 4u) && (!bt->beam_to_axis_dev || !bt->axis_angle_dev || !bt->lut_dev || bt->n_axis < 1 ||
+                          bt->n_axis > 64 || (bt->tile_dev && (bt->tile_w < 1 || bt->tile_h < 1))))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: render stage needs the axis table, LUT and tile size");
+    SLAM_TRY(slam_ws_reserve(ctx, bp.total));
+    uint8_t *b = ctx->ws;
+    frame_ws fws{(uint32_t *)(b + bp.fw[0]), b + bp.fw[1], (uint32_t *)(b + bp.fw[2])};
+    correct_ws cws;
+    cws.bind(b, bp.cw, bp.bl_cap);
+    render_ws rws;
+    rws.bind(b, bp.rw);
+    rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
+    if (stages & 1u) {
+        SLAM_HIP(ctx, hipMemsetAsync(bt->stats_dev, 0, (size_t)F * SLAM_STAT_WORDS * 4, ctx->stream));
+        frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev};
+        SLAM_TRY(frame_decode(ctx, bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, fs, F, bt->max_text_len, fws, bp.nt_max,
+                              rows, bt->stats_dev));
+    }
+    if (stages & 2u) {
+        rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
+        kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev};
+        correct_params prm{bt->cycle, bt->tol, bt->mod_base, 0};
+        SLAM_TRY((correct_rows<uint8_t, uint32_t>(ctx, in, F, cws, prm, out, nullptr, bt->stats_dev)));
+    }
+    if (stages & 4u) {
+        render_params rp{bt->beam_to_axis_dev, bt->axis_angle_dev, bt->n_axis, bt->blur_sigma, bt->use_log,
+                         bt->vmin, bt->vmax, bt->lut_dev, bt->tile_w, bt->tile_h};
+        double *kern;
+        int ks;
+        SLAM_TRY(get_kernel(ctx, bt->blur_sigma, &kern, &ks));
+        SLAM_TRY((pivot_accumulate<uint8_t, uint32_t>(ctx, bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev,
+                                                      bt->row_cap, F, bt->stats_dev, SLAM_STAT_KEPT, rp, rws)));
+        SLAM_TRY(matrix_blur_render(ctx, F, rp, rws, kern, ks, bt->matrix_dev, bt->blurred_dev, bt->tile_dev,
+                                    bt->stats_dev));
+    }
+    return SLAM_OK;
+}

@@ -1,0 +1,459 @@
+// BS-beam index correction: groups -> baselines -> nearest-baseline search -> kept rows.
+//
+// Replaces the data path of bs_beam_correction.py: _detect_groups (:43-47), _identify_baselines
+// (:50-61), _filter_group_corrected (:140-178) / _correct_group (:79-116), driven over a whole
+// table as process_excel_filtered does (:186-198).
+//
+// The reference tries every baseline of the row's group: d = clk - clk_b, k = round(d / CYCLE),
+// resid = |d - k*CYCLE|, keeps those with resid <= TOL and takes the smallest resid, the earliest
+// baseline on ties.  resid is the circular distance between (clk mod CYCLE) and (clk_b mod CYCLE),
+// so the winner is one of the two circular neighbours of clk mod CYCLE among the group's distinct
+// baseline phases.  Each group's phases are sorted once (ties keep the earliest baseline), then
+// every row does one binary search instead of a pass over all baselines.  All integer arithmetic.
+
+#include <type_traits>
+
+#include "pipeline.hpp"
+
+namespace {
+
+constexpr int SORT_CAP = 2048;       // baselines per group sorted in LDS; larger groups use the rank path
+
+template <typename T>
+struct vec4_of;
+template <>
+struct vec4_of<uint8_t> { using type = uchar4; };
+template <>
+struct vec4_of<uint32_t> { using type = uint4; };
+template <>
+struct vec4_of<int32_t> { using type = int4; };
+
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, T v[4])
+{
+    using V = typename vec4_of<T>::type;
+    V q = *reinterpret_cast<const V *>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+
+// boundary / baseline bits of the 4 rows [i0, i0+4) of a frame with n rows
+template <typename T8, typename T32>
+__device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb, uint32_t i0, uint32_t n,
+                                         bool one_group, uint32_t *bound, uint32_t *base)
+{
+    *bound = 0;
+    *base = 0;
+    if (i0 >= n) return;
+    T8 ue[4], fl[4];
+    T32 rs[4];
+    load4(in.ue + fb + i0, ue);
+    if (one_group) {
+        if (i0 == 0) *bound = 1;
+        return;
+    }
+    load4(in.flag + fb + i0, fl);
+    load4(in.rss + fb + i0, rs);
+    T8 pue = 0, pfl = 0;
+    T32 prs = 0;
+    if (i0 > 0) {
+        pue = in.ue[fb + i0 - 1];
+        pfl = in.flag[fb + i0 - 1];
+        prs = in.rss[fb + i0 - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t i = i0 + k;
+        if (i < n) {
+            bool b = (i == 0) || (pue > ue[k]);
+            bool bl = !b && fl[k] == 1 && pfl == 0 && rs[k] == prs;
+            *bound |= (uint32_t)b << k;
+            *base |= (uint32_t)bl << k;
+        }
+        pue = ue[k]; pfl = fl[k]; prs = rs[k];
+    }
+}
+
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
+                                                         uint32_t *rt_nbound, uint32_t *rt_nbase,
+                                                         const uint32_t *stats)
+{
+    __shared__ uint32_t sh[8];
+    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    uint32_t bound, base;
+    row_bits(in, (size_t)f * in.row_cap, tile * ROWS_PER_BLOCK + tid * 4, n, one_group != 0, &bound, &base);
+    uint32_t cb = wave_sum(__popc(bound)), cl = wave_sum(__popc(base));
+    if (lane_id() == 0) { sh[tid >> 6] = cb; sh[4 + (tid >> 6)] = cl; }
+    __syncthreads();
+    if (tid == 0) {
+        rt_nbound[(size_t)f * rt_max + tile] = sh[0] + sh[1] + sh[2] + sh[3];
+        rt_nbase[(size_t)f * rt_max + tile] = sh[4] + sh[5] + sh[6] + sh[7];
+    }
+}
+
+// Per frame: counts per row tile -> exclusive bases in place; totals to stats.
+// a/b are scanned together (b may be null).  In group mode also writes the group-table sentinels.
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, uint32_t rt_max, uint32_t *stats,
+                                                     int stat_a, int stat_b, int keep_stat_b,
+                                                     uint32_t *grp_row, uint32_t *grp_bl, uint32_t grp_stride)
+{
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t nt = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    uint32_t ca = 0, cb = 0;
+    for (uint32_t seg = 0; seg < nt; seg += 1024) {
+        uint32_t t = seg + tid;
+        uint32_t va = t < nt ? a[(size_t)f * rt_max + t] : 0;
+        uint32_t vb = (b && t < nt) ? b[(size_t)f * rt_max + t] : 0;
+        uint32_t ta, tb;
+        uint32_t ea = block_excl_scan(va, sh, &ta);
+        uint32_t eb = block_excl_scan(vb, sh, &tb);
+        if (t < nt) {
+            a[(size_t)f * rt_max + t] = ca + ea;
+            if (b) b[(size_t)f * rt_max + t] = cb + eb;
+        }
+        ca += ta;
+        cb += tb;
+    }
+    if (tid == 0) {
+        stats[f * SLAM_STAT_WORDS + stat_a] = ca;
+        uint32_t nbl = cb;
+        if (b) {
+            if (keep_stat_b) nbl = stats[f * SLAM_STAT_WORDS + stat_b];
+            else stats[f * SLAM_STAT_WORDS + stat_b] = cb;
+        }
+        if (grp_row) {
+            grp_row[(size_t)f * grp_stride + ca] = n;
+            grp_bl[(size_t)f * grp_stride + ca] = nbl;
+        }
+    }
+}
+
+// Group table (first row, first baseline of every group), baseline list, optional gid per row.
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
+                                                      const uint32_t *rt_gbase, const uint32_t *rt_bbase,
+                                                      correct_ws ws, int32_t *gid_out, const uint32_t *stats)
+{
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
+    if (tile * ROWS_PER_BLOCK >= n) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    uint32_t bound, base;
+    row_bits(in, fb, i0, n, one_group != 0, &bound, &base);
+    uint32_t tot;
+    uint32_t packed = __popc(bound) | (__popc(base) << 16);       // both counts fit 16 bits per block
+    uint32_t ex = block_excl_scan(packed, sh, &tot);
+    uint32_t g = rt_gbase[(size_t)f * rt_max + tile] + (ex & 0xFFFFu);      // groups started before this thread's rows
+    uint32_t j = rt_bbase[(size_t)f * rt_max + tile] + (ex >> 16);
+    const size_t gs = (size_t)f * (in.row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t i = i0 + k;
+        if (i >= n) break;
+        if ((bound >> k) & 1u) {
+            ws.grp_row[gs + g] = i;
+            ws.grp_bl[gs + g] = j;
+            g++;
+        }
+        if ((base >> k) & 1u) {
+            ws.bl_clk[bsb + j] = (int32_t)in.clk[fb + i - 1];
+            ws.bl_bs[bsb + j] = (int32_t)in.bs[fb + i];
+            ws.bl_gid[bsb + j] = g - 1;
+            j++;
+        }
+        if (gid_out) gid_out[fb + i] = (int32_t)(g - 1);
+    }
+}
+
+// Per group: sort baseline phases (clk_b mod cycle), keep the earliest baseline of each phase.
+__global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap, int32_t cycle,
+                                                  const uint32_t *stats)
+{
+    __shared__ unsigned long long keys[SORT_CAP];
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+    const size_t gs = (size_t)f * (row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+    for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
+        const uint32_t b0 = ws.grp_bl[gs + g], b1 = ws.grp_bl[gs + g + 1];
+        const uint32_t m = b1 - b0;
+        if (m == 0) {
+            if (tid == 0) ws.grp_nd[gs + g] = 0;
+            continue;
+        }
+        if (m <= SORT_CAP) {
+            uint32_t P = 1;
+            while (P < m) P <<= 1;
+            for (uint32_t i = tid; i < P; i += 256)
+                keys[i] = i < m ? ((unsigned long long)(uint32_t)pymod(ws.bl_clk[bsb + b0 + i], cycle) << 32) | i
+                                : ~0ull;
+            __syncthreads();
+            for (uint32_t k = 2; k <= P; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = tid; i < P; i += 256) {
+                        uint32_t l = i ^ j;
+                        if (l > i) {
+                            unsigned long long a = keys[i], b = keys[l];
+                            bool up = (i & k) == 0;
+                            if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            uint32_t run = 0;                                  // distinct phases written so far
+            for (uint32_t seg = 0; seg < m; seg += 256) {
+                uint32_t i = seg + tid;
+                bool keep = false;
+                unsigned long long key = 0;
+                if (i < m) {
+                    key = keys[i];
+                    keep = (i == 0) || ((uint32_t)(keys[i - 1] >> 32) != (uint32_t)(key >> 32));
+                }
+                uint32_t tot;
+                uint32_t ex = block_excl_scan(keep ? 1u : 0u, sh, &tot);
+                if (keep) {
+                    uint32_t o = run + ex, idx = (uint32_t)key;
+                    ws.srt_rb[bsb + b0 + o] = (uint32_t)(key >> 32);
+                    ws.srt_idx[bsb + b0 + o] = idx;
+                    ws.srt_clk[bsb + b0 + o] = ws.bl_clk[bsb + b0 + idx];
+                    ws.srt_bs[bsb + b0 + o] = ws.bl_bs[bsb + b0 + idx];
+                }
+                run += tot;
+            }
+            if (tid == 0) ws.grp_nd[gs + g] = run;
+            __syncthreads();
+        } else {
+            // rank path: a phase is kept when no earlier baseline has it; its position is the number
+            // of kept phases below it.  O(m^2) per group, for groups too large for the LDS sort.
+            uint32_t *tmp_rb = ws.tmp_a + bsb + b0, *tmp_keep = ws.tmp_b + bsb + b0;
+            for (uint32_t i = tid; i < m; i += 256) tmp_rb[i] = (uint32_t)pymod(ws.bl_clk[bsb + b0 + i], cycle);
+            __syncthreads();
+            for (uint32_t i = tid; i < m; i += 256) {
+                uint32_t rb = tmp_rb[i], keep = 1;
+                for (uint32_t q = 0; q < i; q++)
+                    if (tmp_rb[q] == rb) { keep = 0; break; }
+                tmp_keep[i] = keep;
+            }
+            __syncthreads();
+            uint32_t kept_total = 0;
+            for (uint32_t i = tid; i < m; i += 256) {
+                if (!tmp_keep[i]) continue;
+                uint32_t rb = tmp_rb[i], pos = 0;
+                for (uint32_t q = 0; q < m; q++) pos += (tmp_keep[q] && tmp_rb[q] < rb) ? 1u : 0u;
+                ws.srt_rb[bsb + b0 + pos] = rb;
+                ws.srt_idx[bsb + b0 + pos] = i;
+                ws.srt_clk[bsb + b0 + pos] = ws.bl_clk[bsb + b0 + i];
+                ws.srt_bs[bsb + b0 + pos] = ws.bl_bs[bsb + b0 + i];
+                kept_total++;
+            }
+            uint32_t tot;
+            block_excl_scan(kept_total, sh, &tot);
+            if (tid == 0) ws.grp_nd[gs + g] = tot;
+        }
+    }
+}
+
+template <typename TC>
+struct corr_none;
+template <>
+struct corr_none<uint8_t> { static constexpr uint8_t v = 0xFF; };
+template <>
+struct corr_none<int32_t> { static constexpr int32_t v = -1; };
+
+// Per row: nearest baseline phase of its group -> corrected BS or "none"; kept count per tile.
+template <typename T8, typename T32, typename TC>
+__global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
+                                                       const uint32_t *rt_gbase, correct_ws ws, TC *corr,
+                                                       correct_params prm, uint32_t *rt_nkept,
+                                                       const uint32_t *stats)
+{
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
+    if (tile * ROWS_PER_BLOCK >= n) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    uint32_t bound, base;
+    row_bits(in, fb, i0, n, one_group != 0, &bound, &base);
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+    uint32_t g = rt_gbase[(size_t)f * rt_max + tile] + ex;        // groups started before this thread's rows
+    const size_t gs = (size_t)f * (in.row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+    uint32_t kept = 0;
+    if (i0 < n) {
+        T8 fl[4];
+        T32 ck[4];
+        load4(in.flag + fb + i0, fl);
+        load4(in.clk + fb + i0, ck);
+        TC res[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            res[k] = corr_none<TC>::v;
+            uint32_t i = i0 + k;
+            if (i >= n) continue;
+            if ((bound >> k) & 1u) g++;
+            if (fl[k] == 1) continue;
+            const uint32_t gi = g - 1;
+            const uint32_t nd = ws.grp_nd[gs + gi];
+            if (nd == 0) continue;
+            const uint32_t *rb = ws.srt_rb + bsb + ws.grp_bl[gs + gi];
+            const int32_t clk = (int32_t)ck[k];
+            const uint32_t r = (uint32_t)pymod(clk, prm.cycle);
+            uint32_t lo = 0, hi = nd;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (rb[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            uint32_t is = lo < nd ? lo : 0, ip = lo > 0 ? lo - 1 : nd - 1;
+            uint32_t vs = rb[is], vp = rb[ip];
+            uint32_t xs = vs > r ? vs - r : r - vs, xp = vp > r ? vp - r : r - vp;
+            uint32_t rs_ = min(xs, (uint32_t)prm.cycle - xs), rp_ = min(xp, (uint32_t)prm.cycle - xp);
+            const uint32_t *sidx = ws.srt_idx + bsb + ws.grp_bl[gs + gi];
+            uint32_t w = is, resid = rs_;
+            if (rp_ < rs_ || (rp_ == rs_ && sidx[ip] < sidx[is])) { w = ip; resid = rp_; }
+            if ((int64_t)resid > (int64_t)prm.tol) continue;
+            const size_t wi = bsb + ws.grp_bl[gs + gi] + w;
+            int32_t d = clk - ws.srt_clk[wi];
+            int32_t q = d / prm.cycle, rem = d - q * prm.cycle;
+            if (rem < 0) { rem += prm.cycle; q--; }
+            int64_t twice = 2ll * rem;
+            int32_t kk = twice > prm.cycle ? q + 1 : (twice < prm.cycle ? q : ((q & 1) ? q + 1 : q));
+            res[k] = (TC)pymod(ws.srt_bs[wi] + kk, prm.mod_base);
+            kept++;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i0 + k < n) corr[fb + i0 + k] = res[k];
+    }
+    uint32_t c = wave_sum(kept);
+    __shared__ uint32_t shk[4];
+    if (lane_id() == 0) shk[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) rt_nkept[(size_t)f * rt_max + tile] = shk[0] + shk[1] + shk[2] + shk[3];
+}
+
+template <typename T8, typename T32, typename TC>
+__global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, uint32_t rt_max, const TC *corr,
+                                                         const uint32_t *rt_kbase, kept_out_t<T8, T32> out,
+                                                         const uint32_t *stats)
+{
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
+    if (tile * ROWS_PER_BLOCK >= n) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    TC c[4] = {corr_none<TC>::v, corr_none<TC>::v, corr_none<TC>::v, corr_none<TC>::v};
+    if (i0 < n) load4(corr + fb + i0, c);
+    uint32_t keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (i0 + k < n && c[k] != corr_none<TC>::v) keep |= 1u << k;
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(__popc(keep), sh, &tot);
+    if (!keep) return;
+    size_t o = fb + rt_kbase[(size_t)f * rt_max + tile] + ex;
+    T8 ue[4];
+    T32 rs[4], ck[4];
+    load4(in.ue + fb + i0, ue);
+    load4(in.rss + fb + i0, rs);
+    load4(in.clk + fb + i0, ck);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((keep >> k) & 1u) {
+            out.ue[o] = ue[k];
+            out.bs[o] = (T8)c[k];
+            out.rss[o] = rs[k];
+            out.clk[o] = ck[k];
+            o++;
+        }
+    }
+}
+
+}  // namespace
+
+void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap, size_t off[16])
+{
+    const uint32_t rt_max = (row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    off[0] = p.add((size_t)F * rt_max * 4);
+    off[1] = p.add((size_t)F * rt_max * 4);
+    off[2] = p.add((size_t)F * rt_max * 4);
+    off[3] = p.add((size_t)F * (row_cap + 1) * 4);
+    off[4] = p.add((size_t)F * (row_cap + 1) * 4);
+    off[5] = p.add((size_t)F * (row_cap + 1) * 4);
+    for (int i = 6; i < 13; i++) off[i] = p.add((size_t)F * bl_cap * 4);
+    off[13] = p.add((size_t)F * row_cap * 4);
+    off[14] = p.add((size_t)F * bl_cap * 4);
+    off[15] = p.add((size_t)F * bl_cap * 4);
+}
+
+void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
+{
+    rt_nbound = (uint32_t *)(base + off[0]);
+    rt_nbase = (uint32_t *)(base + off[1]);
+    rt_nkept = (uint32_t *)(base + off[2]);
+    grp_row = (uint32_t *)(base + off[3]);
+    grp_bl = (uint32_t *)(base + off[4]);
+    grp_nd = (uint32_t *)(base + off[5]);
+    bl_clk = (int32_t *)(base + off[6]);
+    bl_bs = (int32_t *)(base + off[7]);
+    bl_gid = (uint32_t *)(base + off[8]);
+    srt_rb = (uint32_t *)(base + off[9]);
+    srt_clk = (int32_t *)(base + off[10]);
+    srt_bs = (int32_t *)(base + off[11]);
+    srt_idx = (uint32_t *)(base + off[12]);
+    corr = (int32_t *)(base + off[13]);
+    tmp_a = (uint32_t *)(base + off[14]);
+    tmp_b = (uint32_t *)(base + off[15]);
+    bl_cap = bl_cap_;
+}
+
+template <typename T8, typename T32>
+int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const correct_ws &ws,
+                 const correct_params &prm, const kept_out_t<T8, T32> &out, int32_t *gid_out, uint32_t *stats)
+{
+    using TC = typename std::conditional<sizeof(T8) == 1, uint8_t, int32_t>::type;
+    if (F == 0) return SLAM_OK;
+    if (prm.cycle <= 0 || prm.mod_base <= 0)
+        return slam_fail(ctx, SLAM_E_INVALID, "cycle and mod_base must be positive");
+    if (sizeof(T8) == 1 && prm.mod_base > 255)
+        return slam_fail(ctx, SLAM_E_RANGE, "mod_base > 255 does not fit the 8-bit beam columns");
+    if (in.row_cap % 16)
+        return slam_fail(ctx, SLAM_E_INVALID, "row_cap must be a multiple of 16");
+    const uint32_t rt_max = (in.row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    dim3 grid(rt_max, F), block(256);
+    TC *corr = reinterpret_cast<TC *>(ws.corr);
+    const int og = prm.explicit_baselines;
+    SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
+                ws.rt_nbase, stats);
+    SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
+                (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, og, ws.grp_row, ws.grp_bl, in.row_cap + 1);
+    SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
+                ws.rt_nbase, ws, gid_out, stats);
+    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(64, F), dim3(256), ws, in.row_cap, prm.cycle, stats);
+    SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
+                corr, prm, ws.rt_nkept, stats);
+    SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,
+                (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+    if (out.ue) {
+        SLAM_LAUNCH(ctx, "rows_emit_kept", (k_rows_emit_kept<T8, T32, TC>), grid, block, in, rt_max, corr,
+                    ws.rt_nkept, out, stats);
+    }
+    return SLAM_OK;
+}
+
+template int correct_rows<uint8_t, uint32_t>(slam_ctx *, const rows_in_t<uint8_t, uint32_t> &, uint32_t,
+                                             const correct_ws &, const correct_params &,
+                                             const kept_out_t<uint8_t, uint32_t> &, int32_t *, uint32_t *);
+template int correct_rows<int32_t, int32_t>(slam_ctx *, const rows_in_t<int32_t, int32_t> &, uint32_t,
+                                            const correct_ws &, const correct_params &,
+                                            const kept_out_t<int32_t, int32_t> &, int32_t *, uint32_t *);

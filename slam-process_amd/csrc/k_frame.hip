@@ -1,0 +1,462 @@
+// Record framing: hex text (or raw bytes) -> 11-byte records FLAG UE BS CLK0..4 RSS0..2.
+//
+// Replaces the data path of _read_bytes + _parse_groups (serial_hex_to_excel_v3.py:18-36, :41-103).
+// The reference scan is sequential: at position i a non-flag byte advances by 1 (not counted), a
+// flag byte whose ten followers carry the right tag bits yields a record and advances by 11, any
+// other flag byte counts as discarded and advances by 1; a flag byte with fewer than 11 bytes
+// left counts once and ends the scan.
+//
+// Parallel form.  The scan visits the orbit of position 0 under next(p) = p+11 (record) or p+1.
+// A wave owns a tile of 64 runs x 48 bytes; each lane turns its run into 64-bit position masks
+// (flag bytes, record starts, walkable positions) and finds the positions an orbit visits with a
+// few carry-propagating 64-bit adds ("flood" through walkable positions, then jump 11 from every
+// visited record start, until nothing changes).  A run is "synchronising" when all 11 possible
+// entry offsets leave it at the same offset -- true for real captures after at most one record --
+// so lanes learn their entry offset from their left neighbour and only the first run of a tile
+// depends on the tile's entry offset.  Pass 1 stores, per tile and entry offset, (exit offset,
+// records, discards); a per-frame scan picks each tile's entry and output offset; pass 2 emits.
+// Non-synchronising data (adversarial byte patterns) takes a slower chained path, same results.
+
+#include "pipeline.hpp"
+
+namespace {
+
+struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t v[2]; };
+
+struct src_view {
+    const uint8_t *p;     // first token character (SRC_TEXT3) or first data byte (SRC_RAW)
+    uint32_t n_src;       // source bytes from p
+    uint32_t nb;          // data bytes
+    bool bad;             // text length cannot be a whole number of "XX " tokens
+};
+
+template <int MODE>
+__device__ __forceinline__ src_view resolve_src(const frame_src &s, uint32_t f)
+{
+    src_view v;
+    const uint8_t *p = s.base + s.off[f];
+    uint32_t n = s.len[f];
+    v.bad = false;
+    if (MODE == SRC_TEXT3) {
+        uint32_t pre = 0;
+        if (n >= 3 && p[0] == 0xC2 && p[1] == 0xAB && p[2] == 0x20) pre = 3;   // leading "« "
+        uint32_t L = n - pre;
+        v.p = p + pre;
+        v.n_src = L;
+        v.nb = (L + 1) / 3;
+        v.bad = (L % 3) == 1;
+    } else {
+        v.p = p;
+        v.n_src = n;
+        v.nb = n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t nib4(uint32_t w)
+{
+    return (w & 0x0F0F0F0Fu) + 9u * ((w >> 6) & 0x01010101u);
+}
+
+// 0x80 in every byte of w that is not an ASCII hex digit
+__device__ __forceinline__ uint32_t not_hex4(uint32_t w)
+{
+    uint32_t t = w ^ 0x30303030u;
+    uint32_t dbad = (t + 0x76767676u) & 0x80808080u;
+    uint32_t u = (w | 0x20202020u) ^ 0x60606060u;
+    uint32_t abad = ((u + 0x79797979u) | ~(u + 0x7F7F7F7Fu)) & 0x80808080u;
+    return (dbad & abad) | (w & 0x80808080u);
+}
+
+__device__ __forceinline__ int hexval(uint32_t c)
+{
+    if (c - '0' < 10u) return (int)(c - '0');
+    uint32_t l = c | 0x20u;
+    if (l - 'a' < 6u) return (int)(l - 'a' + 10);
+    return -1;
+}
+
+// One dword (4 data bytes starting at data index gb) of a frame; zero beyond the end.
+template <int MODE>
+__device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t gb, bool *not_strict)
+{
+    if (gb >= sv.nb) return 0;
+    if (MODE == SRC_TEXT3) {
+        if (gb + 4 < sv.nb) {
+            // 12 text bytes "HL HL HL HL " from a 4-byte aligned 16-byte load + funnel shifts
+            const uint8_t *a = sv.p + 3ull * gb;
+            uint32_t s = (uint32_t)((uintptr_t)a & 3u);
+            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(a - s);
+            uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
+            uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
+            uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
+            uint32_t fail = (not_hex4(t0) & 0x80008080u) | ((t0 ^ 0x00200000u) & 0x00FF0000u) |
+                            (not_hex4(t1) & 0x80800080u) | ((t1 ^ 0x00002000u) & 0x0000FF00u) |
+                            (not_hex4(t2) & 0x00808000u) | ((t2 ^ 0x20000020u) & 0xFF0000FFu);
+            if (fail) *not_strict = true;
+            uint32_t n0 = nib4(t0), n1 = nib4(t1), n2 = nib4(t2);
+            uint32_t b0 = ((n0 & 0xFu) << 4) | ((n0 >> 8) & 0xFu);
+            uint32_t b1 = (((n0 >> 24) & 0xFu) << 4) | (n1 & 0xFu);
+            uint32_t b2 = (((n1 >> 16) & 0xFu) << 4) | ((n1 >> 24) & 0xFu);
+            uint32_t b3 = (((n2 >> 8) & 0xFu) << 4) | ((n2 >> 16) & 0xFu);
+            return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        uint32_t val = 0;
+        for (uint32_t k = 0; k < 4; k++) {
+            uint32_t b = gb + k;
+            if (b >= sv.nb) break;
+            uint32_t o = 3u * b;
+            int h = hexval(sv.p[o]);
+            int l = (o + 1 < sv.n_src) ? hexval(sv.p[o + 1]) : -1;
+            if (h < 0 || l < 0) { *not_strict = true; h = 0; l = 0; }
+            if (o + 2 < sv.n_src && sv.p[o + 2] != 0x20) *not_strict = true;
+            val |= (uint32_t)((h << 4) | l) << (8 * k);
+        }
+        return val;
+    } else {
+        const uint8_t *a = sv.p + gb;
+        if (gb + 8 <= sv.nb) {
+            uint32_t s = (uint32_t)((uintptr_t)a & 3u);
+            const u32x2_a4 q = *reinterpret_cast<const u32x2_a4 *>(a - s);
+            return __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
+        }
+        uint32_t val = 0;
+        for (uint32_t k = 0; k < 4 && gb + k < sv.nb; k++) val |= (uint32_t)a[k] << (8 * k);
+        return val;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fill_tile(uint32_t *tile, const src_view &sv, uint32_t tile_start,
+                                          bool *not_strict)
+{
+    for (uint32_t d = lane_id(); d < (uint32_t)FRAME_TILE_DW; d += 64)
+        tile[d] = load_data_dword<MODE>(sv, tile_start + 4u * d, not_strict);
+}
+
+// ---- per-run position masks -----------------------------------------------------------------------
+struct run_masks {
+    uint64_t ok;      // record starts among the run's 48 positions
+    uint64_t cc;      // flag byte is 0xCC (FLAG = 1)
+    uint64_t rej;     // flag bytes that are neither record starts nor tail positions (each visit = 1 discard)
+    uint64_t tail;    // flag bytes with fewer than 11 bytes left: a visit counts 1 discard and ends the scan
+    uint64_t walk;    // positions the scan leaves by +1
+    uint64_t endbit;  // where a visited tail position sends the orbit (first position past the data)
+};
+
+__device__ __forceinline__ uint32_t movemask4(uint32_t x01) { return (x01 * 0x01020408u) >> 24; }
+
+__device__ __forceinline__ uint32_t zero_bytes4(uint32_t v)   // 0x80 in every zero byte, exact
+{
+    uint32_t y = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(y | v | 0x7F7F7F7Fu);
+}
+
+// `tile` is the wave's LDS tile; `rem` = data bytes from the run's first position to the end (<= 0: none).
+__device__ __forceinline__ run_masks make_masks(const uint32_t *tile, int64_t rem)
+{
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(tile) + lane_id() * 3;
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 q = t4[i];
+        w[4 * i + 0] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+    uint64_t b7 = 0, b6 = 0, zcc = 0, z33 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t x = w[i];
+        b7 |= (uint64_t)movemask4((x >> 7) & 0x01010101u) << (4 * i);
+        b6 |= (uint64_t)movemask4((x >> 6) & 0x01010101u) << (4 * i);
+        zcc |= (uint64_t)movemask4(zero_bytes4(x ^ 0xCCCCCCCCu) >> 7) << (4 * i);
+        z33 |= (uint64_t)movemask4(zero_bytes4(x ^ 0x33333333u) >> 7) << (4 * i);
+    }
+    const uint64_t own = (1ull << FRAME_RUN) - 1;
+    uint64_t m0 = ~b7 & ~b6, m1 = ~b7 & b6, m2 = b7 & ~b6, m3 = b7 & b6;
+    uint64_t c2 = m1 & (m1 >> 1);
+    uint64_t c5 = c2 & (c2 >> 2) & (m1 >> 4);          // five CLK tags in a row
+    uint64_t r3 = m2 & (m2 >> 1) & (m2 >> 2);          // three RSS tags in a row
+    uint64_t cand = (zcc | z33) & own;
+    run_masks m;
+    // bytes past the end are zero (tag 00), so a start whose record would run past the end fails the tags
+    m.ok = cand & (m0 >> 1) & (m3 >> 2) & (c5 >> 3) & (r3 >> 8);
+    m.cc = zcc;
+    m.tail = 0;
+    m.endbit = 0;
+    if (rem < FRAME_RUN + 10 && rem > 0) {
+        uint64_t below = (1ull << rem) - 1;            // rem <= 57
+        uint64_t from = rem > 10 ? ~((1ull << (rem - 10)) - 1) : ~0ull;
+        m.tail = cand & below & from;
+        if (m.tail) m.endbit = 1ull << rem;
+    }
+    m.rej = cand & ~m.ok & ~m.tail;
+    m.walk = own & ~m.ok & ~m.tail;
+    return m;
+}
+
+// All positions (bits 0..58) an orbit entering at the seed positions visits.
+__device__ __forceinline__ uint64_t closure(uint64_t seed, const run_masks &m)
+{
+    uint64_t v = seed;
+    for (int it = 0; it < 12; it++) {
+        uint64_t f = (((m.walk & v) + m.walk) ^ m.walk) | v;   // walk +1 through non-record positions
+        uint64_t n = f | ((f & m.ok) << 11);                   // jump over each visited record
+        if (f & m.tail) n |= m.endbit;
+        if (n == v) break;
+        v = n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t count_valid(uint64_t v, const run_masks &m) { return __popcll(v & m.ok); }
+__device__ __forceinline__ uint32_t count_disc(uint64_t v, const run_masks &m)
+{
+    return __popcll(v & m.rej) + ((v & m.tail) ? 1u : 0u);
+}
+
+constexpr uint32_t UNK = 0xFFu;
+
+// Entry offset of every lane's run given the tile's entry offset for lane 0 (all lanes return).
+// x = exit offset when the run is synchronising, else UNK.  Returns this lane's entry offset;
+// *exit_out receives this lane's exit offset.
+__device__ __forceinline__ uint32_t resolve_entries(const run_masks &m, uint32_t x, uint32_t tile_entry,
+                                                    uint32_t *exit_out)
+{
+    uint32_t r = x;
+    uint32_t entry = UNK;
+    for (int guard = 0; guard < 66; guard++) {
+        uint32_t prev = __shfl_up((int)r, 1, 64);
+        if (lane_id() == 0) prev = tile_entry;
+        entry = prev;
+        if (r == UNK && prev != UNK) {
+            uint64_t v = closure(1ull << prev, m);
+            r = (uint32_t)__builtin_ctzll(v >> FRAME_RUN);
+        }
+        if (!__any(r == UNK || entry == UNK)) break;
+    }
+    *exit_out = r;
+    return entry;
+}
+
+// ---- pass 1: per tile, per entry offset: exit offset, records, discards -------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t nt_max, uint32_t *summ,
+                                                          uint32_t *stats)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
+    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t t = blockIdx.x * 4 + wv;
+    const src_view sv = resolve_src<MODE>(src, f);
+    const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
+    const bool active = t < nt;
+    bool not_strict = false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES] = sv.nb;
+        if (sv.bad) not_strict = true;
+    }
+    uint32_t *tile = lds[wv];
+    const uint32_t tile_start = t * FRAME_TILE;
+    if (active) fill_tile<MODE>(tile, sv, tile_start, &not_strict);
+    if (not_strict) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
+    __syncthreads();
+    if (!active) return;
+
+    const run_masks m = make_masks(tile, (int64_t)sv.nb - (int64_t)tile_start - (int64_t)lane * FRAME_RUN);
+    const uint64_t vall = closure(0x7FFull, m);                  // all 11 entry offsets at once
+    const uint64_t exits = vall >> FRAME_RUN;
+    const bool sync = __popcll(exits) == 1;
+    const uint32_t x = sync ? (uint32_t)__builtin_ctzll(exits) : UNK;
+    const uint64_t syncmask = __ballot(sync);
+    const uint32_t s = syncmask ? (uint32_t)__builtin_ctzll(syncmask) : 64u;   // first synchronising run
+
+    // lanes 0..10 chain entry offset e = lane through runs 0..s (run s included)
+    uint32_t e = lane < 11 ? lane : 0, accv = 0, accd = 0;
+    const uint32_t last = s < 64 ? s : 63;
+    for (uint32_t j = 0; j <= last; j++) {
+        run_masks mj;
+        mj.ok = shfl64(m.ok, j); mj.rej = shfl64(m.rej, j); mj.tail = shfl64(m.tail, j);
+        mj.walk = shfl64(m.walk, j); mj.endbit = shfl64(m.endbit, j); mj.cc = 0;
+        uint64_t v = closure(1ull << e, mj);
+        accv += count_valid(v, mj);
+        accd += count_disc(v, mj);
+        e = (uint32_t)__builtin_ctzll(v >> FRAME_RUN);
+    }
+    // runs after s do not depend on the tile's entry
+    uint32_t restv = 0, restd = 0, tile_exit = e;
+    if (s < 63) {
+        uint32_t r = lane <= s ? ((lane == s) ? x : 0u) : x;      // lanes before s are irrelevant here
+        uint32_t ex;
+        // treat run s as lane "0" of the remaining chain: entry of lane s+1 is x_s
+        uint32_t entry = UNK;
+        for (int guard = 0; guard < 66; guard++) {
+            uint32_t prev = __shfl_up((int)r, 1, 64);
+            entry = prev;
+            if (lane > s && r == UNK && prev != UNK) {
+                uint64_t v = closure(1ull << prev, m);
+                r = (uint32_t)__builtin_ctzll(v >> FRAME_RUN);
+            }
+            if (!__any(lane > s && (r == UNK || entry == UNK))) break;
+        }
+        ex = r;
+        uint32_t cv = 0, cd = 0;
+        if (lane > s) {
+            uint64_t v = closure(1ull << entry, m);
+            cv = count_valid(v, m);
+            cd = count_disc(v, m);
+        }
+        restv = wave_sum(cv);
+        restd = wave_sum(cd);
+        tile_exit = (uint32_t)__shfl((int)ex, 63, 64);
+    }
+    if (lane < 11) {
+        uint32_t exit_e = (s < 63) ? tile_exit : e;
+        summ[((size_t)f * nt_max + t) * FRAME_SUMM_WORDS + lane] =
+            (exit_e << 28) | ((accv + restv) << 16) | (accd + restd);
+    }
+}
+
+// ---- per-frame scan over tiles --------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_frame_scan(const uint32_t *summ, uint32_t nt_max,
+                                                      uint8_t *tile_entry, uint32_t *tile_off, uint32_t *stats)
+{
+    __shared__ uint8_t ent[1025];
+    __shared__ uint32_t sh[17];
+    __shared__ uint32_t pending;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nb = stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES];
+    const uint32_t nt = (nb + FRAME_TILE - 1) / FRAME_TILE;
+    uint32_t carry_e = 0, carry_v = 0, carry_d = 0;
+    for (uint32_t seg = 0; seg < nt; seg += 1024) {
+        const uint32_t t = seg + tid;
+        const bool have = t < nt;
+        const uint32_t *mp = summ + ((size_t)f * nt_max + t) * FRAME_SUMM_WORDS;
+        uint32_t x0 = UNK;
+        if (have) {
+            x0 = mp[0] >> 28;
+            for (int e = 1; e < 11; e++)
+                if ((mp[e] >> 28) != x0) x0 = UNK;
+        }
+        ent[tid + 1] = (uint8_t)x0;
+        if (tid == 0) ent[0] = (uint8_t)carry_e;
+        __syncthreads();
+        for (;;) {                                    // chains through non-synchronising tiles (rare)
+            if (tid == 0) pending = 0;
+            uint32_t ep = ent[tid], mine = ent[tid + 1];
+            __syncthreads();
+            if (have && mine == UNK) {
+                if (ep != UNK) ent[tid + 1] = (uint8_t)(mp[ep] >> 28);
+                else pending = 1;
+            }
+            __syncthreads();
+            if (!pending) break;
+            __syncthreads();
+        }
+        uint32_t e = ent[tid], v = 0, d = 0;
+        if (have) {
+            uint32_t word = mp[e];
+            v = (word >> 16) & 0xFFFu;
+            d = word & 0xFFFFu;
+            tile_entry[(size_t)f * nt_max + t] = (uint8_t)e;
+        }
+        uint32_t totv, totd;
+        uint32_t ex = block_excl_scan(v, sh, &totv);
+        block_excl_scan(d, sh, &totd);
+        if (have) tile_off[(size_t)f * nt_max + t] = carry_v + ex;
+        uint32_t cnt = nt - seg < 1024 ? nt - seg : 1024;
+        carry_e = ent[cnt];
+        carry_v += totv;
+        carry_d += totd;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID] = carry_v;
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_DISCARDED] = carry_d;
+    }
+}
+
+// ---- pass 2: emit records ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_max, const uint8_t *tile_entry,
+                                                     const uint32_t *tile_off, rows_out out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
+    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t t = blockIdx.x * 4 + wv;
+    const src_view sv = resolve_src<MODE>(src, f);
+    const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
+    const bool active = t < nt;
+    bool not_strict = false;
+    uint32_t *tile = lds[wv];
+    const uint32_t tile_start = t * FRAME_TILE;
+    if (active) fill_tile<MODE>(tile, sv, tile_start, &not_strict);
+    __syncthreads();
+    if (!active) return;
+
+    const run_masks m = make_masks(tile, (int64_t)sv.nb - (int64_t)tile_start - (int64_t)lane * FRAME_RUN);
+    const uint64_t exits = closure(0x7FFull, m) >> FRAME_RUN;
+    const uint32_t x = __popcll(exits) == 1 ? (uint32_t)__builtin_ctzll(exits) : UNK;
+    uint32_t ex;
+    const uint32_t entry = resolve_entries(m, x, tile_entry[(size_t)f * nt_max + t], &ex);
+    const uint64_t v = closure(1ull << entry, m);
+    uint64_t starts = v & m.ok;
+    const uint32_t cnt = __popcll(starts);
+    const uint32_t inc = wave_incl_scan(cnt);
+    size_t o = (size_t)f * out.row_cap + tile_off[(size_t)f * nt_max + t] + (inc - cnt);
+    const uint32_t lane_byte = lane * FRAME_RUN;
+    while (starts) {
+        uint32_t p = (uint32_t)__builtin_ctzll(starts);
+        starts &= starts - 1;
+        uint32_t off = lane_byte + p, sh = off & 3u, wi = off >> 2;
+        uint32_t w0 = tile[wi], w1 = tile[wi + 1], w2 = tile[wi + 2], w3 = tile[wi + 3];
+        uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        uint32_t d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        uint32_t d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        out.flag[o] = (uint8_t)((m.cc >> p) & 1u);
+        out.ue[o] = (uint8_t)((d0 >> 8) & 63u);
+        out.bs[o] = (uint8_t)((d0 >> 16) & 63u);
+        out.clk[o] = ((d0 >> 24) & 63u) | ((d1 & 63u) << 6) | (((d1 >> 8) & 63u) << 12) |
+                     (((d1 >> 16) & 63u) << 18) | (((d1 >> 24) & 63u) << 24);
+        out.rss[o] = (d2 & 63u) | (((d2 >> 8) & 63u) << 6) | (((d2 >> 16) & 63u) << 12);
+        o++;
+    }
+}
+
+}  // namespace
+
+uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
+{
+    uint64_t nb = mode == SRC_TEXT3 ? ((uint64_t)max_src_len + 1) / 3 : max_src_len;
+    uint32_t nt = (uint32_t)((nb + FRAME_TILE - 1) / FRAME_TILE);
+    return nt ? nt : 1;
+}
+
+void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[3])
+{
+    off[0] = p.add((size_t)F * nt_max * FRAME_SUMM_WORDS * sizeof(uint32_t));
+    off[1] = p.add((size_t)F * nt_max);
+    off[2] = p.add((size_t)F * nt_max * sizeof(uint32_t));
+}
+
+int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t max_src_len,
+                 const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats)
+{
+    (void)max_src_len;
+    if (F == 0) return SLAM_OK;
+    dim3 grid((nt_max + 3) / 4, F), block(256);
+    if (mode == SRC_TEXT3) {
+        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats);
+    } else {
+        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_RAW>), grid, block, src, nt_max, ws.summ, stats);
+    }
+    SLAM_LAUNCH(ctx, "frame_scan", k_frame_scan, dim3(F), dim3(1024), ws.summ, nt_max, ws.tile_entry,
+                ws.tile_off, stats);
+    if (mode == SRC_TEXT3) {
+        SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_TEXT3>), grid, block, src, nt_max, ws.tile_entry,
+                    ws.tile_off, out);
+    } else {
+        SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_RAW>), grid, block, src, nt_max, ws.tile_entry,
+                    ws.tile_off, out);
+    }
+    return SLAM_OK;
+}

@@ -1,0 +1,441 @@
+// Angle mapping + mean pivot, NaN-aware Gaussian blur, colour scale and mesh raster.
+//
+// Replaces the data path of excel_heatmap_v3.py: map_angles (:264-280), compute_rssi_matrix
+// (:286-314), gaussian_blur_nan_aware (:336-368) and generate_heatmap's scale / colormap /
+// pcolormesh steps (:403-456, _edges :430-440).
+//
+// The pivot is an exact integer sum and count per (AoD axis, AoA axis) cell, accumulated in LDS
+// per workgroup and merged with integer atomics, so the result does not depend on arrival order;
+// the mean is one f64 divide per cell.  Float steps are f64 in the reference's operation order
+// (the library is built with -ffp-contract=off so no multiply-add is fused).
+
+#include "pipeline.hpp"
+
+namespace {
+
+constexpr int PIVOT_CHUNK = 16384;     // rows per workgroup of the pivot
+constexpr int MAX_AXIS = 64;
+constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
+
+template <typename T>
+struct v4;
+template <>
+struct v4<uint8_t> { using type = uchar4; };
+template <>
+struct v4<uint32_t> { using type = uint4; };
+template <>
+struct v4<int32_t> { using type = int4; };
+
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
+                                                const uint32_t *stats, int stat_word, const int8_t *beam_to_axis,
+                                                int n_axis, unsigned long long *gsum, uint32_t *gcnt)
+{
+    __shared__ unsigned long long ssum[MAX_CELLS];
+    __shared__ uint32_t scnt[MAX_CELLS];
+    __shared__ int8_t b2a[64];
+    const uint32_t f = blockIdx.y, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + stat_word];
+    const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
+    if (r0 >= n) return;
+    const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
+    const int cells = n_axis * n_axis;
+    for (int i = tid; i < cells; i += 256) { ssum[i] = 0; scnt[i] = 0; }
+    if (tid < 64) b2a[tid] = beam_to_axis[tid];
+    __syncthreads();
+    const size_t fb = (size_t)f * row_cap;
+    for (uint32_t i0 = r0 + tid * 4; i0 < r1; i0 += 1024) {
+        using V8 = typename v4<T8>::type;
+        using V32 = typename v4<T32>::type;
+        V8 u = *reinterpret_cast<const V8 *>(ue + fb + i0);
+        V8 b = *reinterpret_cast<const V8 *>(bs + fb + i0);
+        V32 r = *reinterpret_cast<const V32 *>(rss + fb + i0);
+        const int64_t uu[4] = {(int64_t)u.x, (int64_t)u.y, (int64_t)u.z, (int64_t)u.w};
+        const int64_t bb[4] = {(int64_t)b.x, (int64_t)b.y, (int64_t)b.z, (int64_t)b.w};
+        const int64_t rr[4] = {(int64_t)r.x, (int64_t)r.y, (int64_t)r.z, (int64_t)r.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k >= r1) break;
+            if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
+            int c = b2a[uu[k]], rw = b2a[bb[k]];
+            if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
+            int cell = rw * n_axis + c;
+            atomicAdd(&ssum[cell], (unsigned long long)rr[k]);
+            atomicAdd(&scnt[cell], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < cells; i += 256) {
+        uint32_t c = scnt[i];
+        if (c) {
+            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], ssum[i]);
+            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], c);
+        }
+    }
+}
+
+// ---- small-matrix device routines (one workgroup of 256 threads) --------------------------------------
+
+__device__ __forceinline__ bool finite_d(double v) { return !(isnan(v) || isinf(v)); }
+
+// out[i*w+j] = normalised convolution of in (h x w, row stride w) with kern (ks x ks), edge padding.
+__device__ void blur_block(const double *in, int h, int w, const double *kern, int ks, double *out)
+{
+    const int p = ks / 2;
+    for (int c = threadIdx.x; c < h * w; c += blockDim.x) {
+        const int i = c / w, j = c % w;
+        double num = 0.0, den = 0.0;
+        for (int a = 0; a < ks; a++) {
+            int ii = i + a - p;
+            ii = ii < 0 ? 0 : (ii >= h ? h - 1 : ii);
+            for (int b = 0; b < ks; b++) {
+                int jj = j + b - p;
+                jj = jj < 0 ? 0 : (jj >= w ? w - 1 : jj);
+                const double v = in[ii * w + jj];
+                const bool fin = finite_d(v);
+                const double wgt = kern[a * ks + b] * (fin ? 1.0 : 0.0);
+                num += (fin ? v : 0.0) * wgt;
+                den += wgt;
+            }
+        }
+        out[c] = den > 1e-12 ? num / den : __longlong_as_double(0x7FF8000000000000ll);
+    }
+}
+
+// finite min / max of m[0..n) across the block; sh needs 2*256 doubles.  Returns false when none is finite.
+__device__ bool block_minmax(const double *m, int n, double *sh, double *mn, double *mx)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        double v = m[c];
+        if (finite_d(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
+    }
+    sh[threadIdx.x] = lo;
+    sh[256 + threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[threadIdx.x] = fmin(sh[threadIdx.x], sh[threadIdx.x + s]);
+            sh[256 + threadIdx.x] = fmax(sh[256 + threadIdx.x], sh[256 + threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    *mn = sh[0];
+    *mx = sh[256];
+    __syncthreads();
+    return *mn <= *mx;
+}
+
+// _edges (:430-440) of v[0..n) into e[0..n]
+__device__ void edges_of(const double *v, int n, double *e)
+{
+    if (n == 1) { e[0] = v[0] - 0.5; e[1] = v[0] + 0.5; return; }
+    for (int i = 1; i < n; i++) e[i] = (v[i - 1] + v[i]) / 2.0;
+    e[0] = v[0] - (v[1] - v[0]) / 2.0;
+    e[n] = v[n - 1] + (v[n - 1] - v[n - 2]) / 2.0;
+}
+
+// pixel -> cell index along one axis; flip = true samples from the top edge downwards
+__device__ void axis_map(const double *e, int n, int npix, bool flip, int16_t *map)
+{
+    const double step = (e[n] - e[0]) / (double)npix;
+    for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+        const double t = ((double)p + 0.5) * step;
+        const double x = flip ? e[n] - t : e[0] + t;
+        int lo = 0, hi = n + 1;                 // first edge > x
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (e[mid] <= x) lo = mid + 1; else hi = mid;
+        }
+        int c = lo - 1;
+        c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+        map[p] = (int16_t)c;
+    }
+}
+
+// scale + colour of a compact h x w matrix `m` (row stride w) -> cells RGBA; returns limits used.
+__device__ void colour_block(const double *m, int h, int w, int use_log, double vmin, double vmax,
+                             double mn, double mx, const uint8_t *lut, uint8_t *cells, double *lo_out,
+                             double *hi_out)
+{
+    double lo, hi, tlo = 0.0, span;
+    if (use_log) {
+        lo = isnan(vmin) ? (mn - mn + 1e-6) : (vmin - mn + 1e-6);
+        hi = isnan(vmax) ? (mx - mn + 1e-6) : (vmax - mn + 1e-6);
+        tlo = log10(lo);
+        span = log10(hi) - tlo;
+    } else {
+        lo = isnan(vmin) ? mn : vmin;
+        hi = isnan(vmax) ? mx : vmax;
+        span = hi - lo;
+    }
+    *lo_out = lo;
+    *hi_out = hi;
+    for (int c = threadIdx.x; c < h * w; c += blockDim.x) {
+        const double v = m[c];
+        uchar4 px = make_uchar4(255, 255, 255, 0);           // set_bad((1,1,1,0)) (:447)
+        if (finite_d(v)) {
+            double nrm;
+            if (use_log) nrm = span != 0.0 ? (log10(v - mn + 1e-6) - tlo) / span : 0.0;
+            else nrm = span != 0.0 ? (v - lo) / span : 0.0;
+            double x = floor(nrm * 256.0);
+            int idx = isnan(x) ? 0 : (x < 0.0 ? 0 : (x > 255.0 ? 255 : (int)x));
+            px = make_uchar4(lut[idx * 3], lut[idx * 3 + 1], lut[idx * 3 + 2], 255);
+        }
+        reinterpret_cast<uchar4 *>(cells)[c] = px;
+    }
+}
+
+__device__ __forceinline__ void put_f64_stat(uint32_t *stats, int lo_word, double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    stats[lo_word] = (uint32_t)u;
+    stats[lo_word + 1] = (uint32_t)(u >> 32);
+}
+
+// One workgroup per frame: sum/cnt -> mean grid -> compact -> blur -> scale -> cells + pixel maps.
+__global__ __launch_bounds__(256) void k_frame_matrix(render_params rp, render_ws ws, const double *kern, int ks,
+                                                       double *matrix, double *blurred, uint32_t *stats)
+{
+    __shared__ double cm[MAX_CELLS];
+    __shared__ double bm[MAX_CELLS];
+    __shared__ double red[512];
+    __shared__ double ang_r[MAX_AXIS], ang_c[MAX_AXIS], edge[MAX_AXIS + 1];
+    __shared__ uint32_t rowp[MAX_AXIS], colp[MAX_AXIS];
+    __shared__ int ridx[MAX_AXIS], cidx[MAX_AXIS];
+    __shared__ int s_h, s_w;
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const int na = rp.n_axis;
+    const unsigned long long *sum = ws.sum + (size_t)f * MAX_CELLS;
+    const uint32_t *cnt = ws.cnt + (size_t)f * MAX_CELLS;
+    uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    if (tid < MAX_AXIS) { rowp[tid] = 0; colp[tid] = 0; }
+    __syncthreads();
+    for (int c = tid; c < na * na; c += 256) {
+        const uint32_t k = cnt[c];
+        const double mean = k ? (double)(long long)sum[c] / (double)k : __longlong_as_double(0x7FF8000000000000ll);
+        if (matrix) matrix[(size_t)f * na * na + c] = mean;
+        if (k) { rowp[c / na] = 1; colp[c % na] = 1; }
+    }
+    __syncthreads();
+    if (tid < 64) {                                        // compact index lists of the axes that occur
+        const bool rp_ = (int)tid < na && rowp[tid], cp_ = (int)tid < na && colp[tid];
+        const unsigned long long rm = __ballot(rp_), cmk = __ballot(cp_);
+        const unsigned long long below = (1ull << tid) - 1;
+        if (rp_) { int k = __popcll(rm & below); ridx[k] = tid; ang_r[k] = rp.axis_angle[tid]; }
+        if (cp_) { int k = __popcll(cmk & below); cidx[k] = tid; ang_c[k] = rp.axis_angle[tid]; }
+        if (tid == 0) { s_h = __popcll(rm); s_w = __popcll(cmk); }
+    }
+    __syncthreads();
+    const int h = s_h, w = s_w;
+    if (tid == 0) { st[SLAM_STAT_N_AOD] = h; st[SLAM_STAT_N_AOA] = w; }
+    if (h == 0 || w == 0) {
+        if (tid == 0) st[SLAM_STAT_ALLNAN] = 1;
+        return;
+    }
+    for (int c = tid; c < h * w; c += 256) {
+        const int src = ridx[c / w] * na + cidx[c % w];
+        const uint32_t k = cnt[src];
+        cm[c] = k ? (double)(long long)sum[src] / (double)k : __longlong_as_double(0x7FF8000000000000ll);
+    }
+    __syncthreads();
+    const double *fin = cm;
+    if (ks > 1) {
+        blur_block(cm, h, w, kern, ks, bm);
+        __syncthreads();
+        fin = bm;
+    }
+    if (blurred)
+        for (int c = tid; c < h * w; c += 256) blurred[(size_t)f * na * na + c] = fin[c];
+    double mn, mx;
+    const bool any = block_minmax(fin, h * w, red, &mn, &mx);
+    uint8_t *cells = ws.cells + (size_t)f * MAX_CELLS * 4;
+    if (!any) {
+        if (tid == 0) st[SLAM_STAT_ALLNAN] = 1;
+        return;
+    }
+    double lo, hi;
+    colour_block(fin, h, w, rp.use_log, rp.vmin, rp.vmax, mn, mx, rp.lut, cells, &lo, &hi);
+    if (tid == 0) { put_f64_stat(st, SLAM_STAT_VMIN_LO, lo); put_f64_stat(st, SLAM_STAT_VMAX_LO, hi); }
+    if (tid == 0) edges_of(ang_c, w, edge);
+    __syncthreads();
+    axis_map(edge, w, rp.W, false, ws.colmap + (size_t)f * rp.W);
+    __syncthreads();
+    if (tid == 0) edges_of(ang_r, h, edge);
+    __syncthreads();
+    axis_map(edge, h, rp.H, true, ws.rowmap + (size_t)f * rp.H);
+}
+
+// tile[py][px] = cells[rowmap[py]][colmap[px]]; 4 pixels (16 bytes) per thread
+__global__ __launch_bounds__(256) void k_raster(const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap,
+                                                 int W, int H, const uint32_t *stats, uint8_t *tile)
+{
+    const uint32_t f = blockIdx.y;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;           // group of 4 pixels
+    const uint32_t wq = (uint32_t)(W + 3) / 4;
+    if (q >= wq * (uint32_t)H) return;
+    const uint32_t py = q / wq, px0 = (q % wq) * 4;
+    const uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    const bool blank = st[SLAM_STAT_ALLNAN] != 0;
+    const int w = (int)st[SLAM_STAT_N_AOA];
+    const uchar4 *c4 = reinterpret_cast<const uchar4 *>(cells) + (size_t)f * MAX_CELLS;
+    uchar4 out[4];
+    const int row = blank ? 0 : rowmap[(size_t)f * H + py];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[k] = make_uchar4(255, 255, 255, 0);
+        if (!blank && (int)(px0 + k) < W) out[k] = c4[row * w + colmap[(size_t)f * W + px0 + k]];
+    }
+    uchar4 *dst = reinterpret_cast<uchar4 *>(tile) + ((size_t)f * H + py) * W + px0;
+    if ((W & 3) == 0) {
+        uint4 v;
+        v.x = *reinterpret_cast<uint32_t *>(&out[0]); v.y = *reinterpret_cast<uint32_t *>(&out[1]);
+        v.z = *reinterpret_cast<uint32_t *>(&out[2]); v.w = *reinterpret_cast<uint32_t *>(&out[3]);
+        *reinterpret_cast<uint4 *>(dst) = v;
+    } else {
+        for (int k = 0; k < 4 && (int)(px0 + k) < W; k++) dst[k] = out[k];
+    }
+}
+
+// ---- standalone stages on caller matrices ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_only(const double *in, int h, int w, const double *kern, int ks,
+                                                    double *out)
+{
+    // one workgroup; strides over all cells
+    blur_block(in, h, w, kern, ks, out);
+}
+
+__global__ __launch_bounds__(256) void k_mean_only(const unsigned long long *sum, const uint32_t *cnt, int cells,
+                                                    double *matrix)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cells) return;
+    const uint32_t k = cnt[c];
+    matrix[c] = k ? (double)(long long)sum[c] / (double)k : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+__global__ __launch_bounds__(256) void k_render_only(const double *mat, int h, int w, const double *aod,
+                                                      const double *aoa, int use_log, double vmin, double vmax,
+                                                      const uint8_t *lut, uint8_t *cells, int16_t *colmap,
+                                                      int16_t *rowmap, int W, int H, uint32_t *stats)
+{
+    __shared__ double red[512];
+    __shared__ double edge[MAX_AXIS + 1];
+    const uint32_t tid = threadIdx.x;
+    double mn, mx;
+    if (tid == 0) { stats[SLAM_STAT_N_AOD] = h; stats[SLAM_STAT_N_AOA] = w; }
+    const bool any = block_minmax(mat, h * w, red, &mn, &mx);
+    if (!any) {
+        if (tid == 0) stats[SLAM_STAT_ALLNAN] = 1;
+        return;
+    }
+    double lo, hi;
+    colour_block(mat, h, w, use_log, vmin, vmax, mn, mx, lut, cells, &lo, &hi);
+    if (tid == 0) { put_f64_stat(stats, SLAM_STAT_VMIN_LO, lo); put_f64_stat(stats, SLAM_STAT_VMAX_LO, hi); }
+    if (tid == 0) edges_of(aoa, w, edge);
+    __syncthreads();
+    axis_map(edge, w, W, false, colmap);
+    __syncthreads();
+    if (tid == 0) edges_of(aod, h, edge);
+    __syncthreads();
+    axis_map(edge, h, H, true, rowmap);
+}
+
+}  // namespace
+
+void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, size_t off[5])
+{
+    off[0] = p.add((size_t)F * MAX_CELLS * 8);
+    off[1] = p.add((size_t)F * MAX_CELLS * 4);
+    off[2] = p.add((size_t)F * MAX_CELLS * 4);
+    off[3] = p.add((size_t)F * (size_t)(W > 0 ? W : 1) * 2);
+    off[4] = p.add((size_t)F * (size_t)(H > 0 ? H : 1) * 2);
+}
+
+void render_ws::bind(uint8_t *base, const size_t off[5])
+{
+    sum = (unsigned long long *)(base + off[0]);
+    cnt = (uint32_t *)(base + off[1]);
+    cells = base + off[2];
+    colmap = (int16_t *)(base + off[3]);
+    rowmap = (int16_t *)(base + off[4]);
+}
+
+template <typename T8, typename T32>
+int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap, uint32_t F,
+                     const uint32_t *stats, int stat_word, const render_params &rp, const render_ws &ws)
+{
+    if (F == 0) return SLAM_OK;
+    if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
+    SLAM_HIP(ctx, hipMemsetAsync(ws.sum, 0, (size_t)F * MAX_CELLS * 8, ctx->stream));
+    SLAM_HIP(ctx, hipMemsetAsync(ws.cnt, 0, (size_t)F * MAX_CELLS * 4, ctx->stream));
+    dim3 grid((row_cap + PIVOT_CHUNK - 1) / PIVOT_CHUNK, F), block(256);
+    SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
+                rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt);
+    return SLAM_OK;
+}
+
+template int pivot_accumulate<uint8_t, uint32_t>(slam_ctx *, const uint8_t *, const uint8_t *, const uint32_t *,
+                                                 uint32_t, uint32_t, const uint32_t *, int, const render_params &,
+                                                 const render_ws &);
+template int pivot_accumulate<int32_t, int32_t>(slam_ctx *, const int32_t *, const int32_t *, const int32_t *,
+                                                uint32_t, uint32_t, const uint32_t *, int, const render_params &,
+                                                const render_ws &);
+
+// Gaussian kernel of gaussian_kernel (:320-333), built on the host into `k` (size*size doubles); returns size.
+int slam_gaussian_kernel_host(double sigma, std::vector<double> &k)
+{
+    if (sigma <= 0) { k.assign(1, 1.0); return 1; }
+    int size = (int)fmax(3.0, ceil(6.0 * sigma));
+    if (size % 2 == 0) size++;
+    const int c = size / 2;
+    k.resize((size_t)size * size);
+    double total = 0.0;
+    for (int y = -c; y <= c; y++)
+        for (int x = -c; x <= c; x++) {
+            double v = exp(-(double)(x * x + y * y) / (2.0 * sigma * sigma));
+            k[(size_t)(y + c) * size + (x + c)] = v;
+            total += v;
+        }
+    for (auto &v : k) v /= total;
+    return size;
+}
+
+int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const render_ws &ws, const double *kern,
+                       int ks, double *matrix, double *blurred, uint8_t *tile, uint32_t *stats)
+{
+    if (F == 0) return SLAM_OK;
+    SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(256), rp, ws, kern, ks, matrix, blurred, stats);
+    if (tile) {
+        const uint32_t groups = (uint32_t)((rp.W + 3) / 4) * (uint32_t)rp.H;
+        SLAM_LAUNCH(ctx, "raster", k_raster, dim3((groups + 255) / 256, F), dim3(256), ws.cells, ws.colmap,
+                    ws.rowmap, rp.W, rp.H, stats, tile);
+    }
+    return SLAM_OK;
+}
+
+int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt, int cells, double *matrix)
+{
+    SLAM_LAUNCH(ctx, "mean", k_mean_only, dim3((cells + 255) / 256), dim3(256), sum, cnt, cells, matrix);
+    return SLAM_OK;
+}
+
+int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern, int ks, double *out)
+{
+    SLAM_LAUNCH(ctx, "blur", k_blur_only, dim3(1), dim3(256), in, h, w, kern, ks, out);
+    return SLAM_OK;
+}
+
+int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa, int use_log,
+                double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,
+                int16_t *colmap, int16_t *rowmap, uint32_t *stats)
+{
+    SLAM_LAUNCH(ctx, "render_cells", k_render_only, dim3(1), dim3(256), mat, h, w, aod, aoa, use_log, vmin, vmax,
+                lut, cells, colmap, rowmap, W, H, stats);
+    if (tile) {
+        const uint32_t groups = (uint32_t)((W + 3) / 4) * (uint32_t)H;
+        SLAM_LAUNCH(ctx, "raster", k_raster, dim3((groups + 255) / 256, 1), dim3(256), cells, colmap, rowmap, W, H,
+                    stats, tile);
+    }
+    return SLAM_OK;
+}

@@ -1,0 +1,122 @@
+// Internal stage launchers shared by the C-ABI entry points (host side).
+#pragma once
+#include "common.hpp"
+
+// ---- record framing ----------------------------------------------------------------------------
+constexpr int FRAME_RUN = 48;                    // data bytes owned by one lane
+constexpr int FRAME_TILE = 64 * FRAME_RUN;       // 3072 data bytes per wave tile
+constexpr int FRAME_TILE_DW = FRAME_TILE / 4 + 4;  // tile + 16 halo bytes, in dwords
+constexpr int FRAME_SUMM_WORDS = 11;             // one packed word per entry offset 0..10
+
+enum { SRC_TEXT3 = 0, SRC_RAW = 1 };
+
+struct frame_src {
+    const uint8_t *base;        // device: text (SRC_TEXT3) or data bytes (SRC_RAW) of all frames
+    const uint64_t *off;        // device [F]
+    const uint32_t *len;        // device [F]
+};
+
+struct frame_ws {               // device scratch of the framing stage
+    uint32_t *summ;             // [F * nt_max * 11]
+    uint8_t *tile_entry;        // [F * nt_max]
+    uint32_t *tile_off;         // [F * nt_max]
+    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[3]);
+};
+
+struct rows_out {               // decoded records, frame f at f*row_cap
+    uint8_t *flag, *ue, *bs;
+    uint32_t *rss, *clk;
+    uint32_t row_cap;
+};
+
+// Decode F frames: source -> records + stats words NBYTES / NOT_STRICT / VALID / DISCARDED.
+int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t max_src_len,
+                 const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats);
+uint32_t frame_tiles_for(int mode, uint32_t max_src_len);
+
+// ---- correction ----------------------------------------------------------------------------------
+constexpr int ROWS_PER_BLOCK = 1024;             // 256 threads x 4 rows
+
+template <typename T8, typename T32>
+struct rows_in_t {
+    const T8 *flag, *ue, *bs;
+    const T32 *rss, *clk;
+    uint32_t row_cap;           // per-frame stride
+};
+
+template <typename T8, typename T32>
+struct kept_out_t {
+    T8 *ue, *bs;
+    T32 *rss, *clk;
+};
+
+struct correct_ws {
+    uint32_t *rt_nbound, *rt_nbase, *rt_nkept;   // [F * rt_max] per row-tile counts, then exclusive bases
+    uint32_t *grp_row, *grp_bl, *grp_nd;         // [F * (row_cap + 1)] group tables
+    int32_t *bl_clk, *bl_bs;                     // [F * bl_cap] baselines in row order
+    uint32_t *bl_gid;                            // [F * bl_cap]
+    uint32_t *srt_rb;                            // [F * bl_cap] per group: distinct clk_b mod cycle, ascending
+    int32_t *srt_clk, *srt_bs;                   // winner payload in the same order
+    uint32_t *srt_idx;                           // baseline index within its group (tie-break)
+    int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
+    uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
+    uint32_t bl_cap;                             // baselines per frame the arrays can hold
+    static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }
+    static void plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap, size_t off[16]);
+    void bind(uint8_t *base, const size_t off[16], uint32_t bl_cap);
+};
+
+struct correct_params {
+    int32_t cycle, tol, mod_base;
+    int explicit_baselines;     // 1: one group, baselines preloaded into bl_clk/bl_bs, count in stats BASELINES
+};
+
+template <typename T8, typename T32>
+int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const correct_ws &ws,
+                 const correct_params &prm, const kept_out_t<T8, T32> &out, int32_t *gid_out,
+                 uint32_t *stats);
+
+// ---- pivot / blur / raster ---------------------------------------------------------------------
+struct render_params {
+    const int8_t *beam_to_axis;     // device [64]
+    const double *axis_angle;       // device [n_axis]
+    int32_t n_axis;
+    double sigma;
+    int32_t use_log;
+    double vmin, vmax;
+    const uint8_t *lut;             // device [768]
+    int32_t W, H;
+};
+
+struct render_ws {
+    unsigned long long *sum;        // [F * 4096]
+    uint32_t *cnt;                  // [F * 4096]
+    uint8_t *cells;                 // [F * 4096 * 4] RGBA per compact cell
+    int16_t *colmap, *rowmap;       // [F * W], [F * H] pixel -> compact cell index
+    static void plan(ws_plan &p, uint32_t F, int W, int H, size_t off[5]);
+    void bind(uint8_t *base, const size_t off[5]);
+};
+
+template <typename T8, typename T32>
+int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
+                     uint32_t F, const uint32_t *stats, int stat_word, const render_params &rp,
+                     const render_ws &ws);
+// sum/cnt -> mean matrix (full axis grid), compact + blur, scale, colours, index maps, tile.
+// kern is the ks x ks Gaussian kernel on the device (ks == 1: no blur).
+int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const render_ws &ws, const double *kern,
+                       int ks, double *matrix, double *blurred, uint8_t *tile, uint32_t *stats);
+
+// standalone small-matrix stages used by slam_pivot_mean / slam_blur_nan / slam_render (device pointers)
+int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt, int cells, double *matrix);
+int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern, int ks, double *out);
+int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa, int use_log,
+                double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,
+                int16_t *colmap, int16_t *rowmap, uint32_t *stats);
+int slam_gaussian_kernel_host(double sigma, std::vector<double> &k);
+
+// ---- general tokenizer ---------------------------------------------------------------------------
+// text -> bytes with the reference's exact token rules; n_out_dev receives the count; ws holds
+// tokenize_ws_bytes(n_text) bytes of scratch.
+int tokenize_general(slam_ctx *ctx, const uint8_t *text_dev, size_t n_text, uint8_t *bytes_dev, uint32_t *n_out_dev,
+                     uint8_t *ws);
+size_t tokenize_ws_bytes(size_t n_text);

@@ -1,0 +1,182 @@
+"""ctypes binding of libslamhip.so (include/slamhip.h).
+
+There is no CPU fallback: if the library is missing or no GPU is present the
+calls raise.  Importing this module never touches the GPU; `ctx()` does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+
+OK, E_INVALID, E_HIP, E_CAPACITY, E_EMPTY, E_ALLNAN, E_RANGE = 0, -1, -2, -3, -4, -5, -6
+STAT_WORDS = 16
+(STAT_NBYTES, STAT_NOT_STRICT, STAT_VALID, STAT_DISCARDED, STAT_GROUPS, STAT_BASELINES, STAT_KEPT,
+ STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI) = range(14)
+
+EXPORTS = [
+    "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_sync", "slam_last_error", "slam_version",
+    "slam_hex_unpack", "slam_parse_records", "slam_parse_text", "slam_correct", "slam_pivot_mean",
+    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_reserve_workspace",
+    "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev",
+    "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
+]
+
+
+class SlamError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libslamhip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Batch(C.Structure):
+    """struct slam_batch"""
+    _fields_ = [
+        ("text_dev", C.c_void_p), ("text_off_dev", C.c_void_p), ("text_len_dev", C.c_void_p),
+        ("n_frames", C.c_uint32), ("max_text_len", C.c_uint32), ("src_is_bytes", C.c_uint32),
+        ("cycle", C.c_int32), ("tol", C.c_int32), ("mod_base", C.c_int32),
+        ("beam_to_axis_dev", C.c_void_p), ("axis_angle_dev", C.c_void_p), ("n_axis", C.c_int32),
+        ("blur_sigma", C.c_double), ("use_log", C.c_int32), ("vmin", C.c_double), ("vmax", C.c_double),
+        ("lut_dev", C.c_void_p), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
+        ("row_cap", C.c_uint32),
+        ("flag_dev", C.c_void_p), ("ue_dev", C.c_void_p), ("bs_dev", C.c_void_p),
+        ("rss_dev", C.c_void_p), ("clk_dev", C.c_void_p),
+        ("kept_ue_dev", C.c_void_p), ("kept_bs_dev", C.c_void_p),
+        ("kept_rss_dev", C.c_void_p), ("kept_clk_dev", C.c_void_p),
+        ("stats_dev", C.c_void_p), ("matrix_dev", C.c_void_p), ("blurred_dev", C.c_void_p),
+        ("tile_dev", C.c_void_p),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the shared library and declare every prototype (no GPU call)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python slam-process_amd/slamhip/build.py` "
+                "(there is no CPU fallback for this path)")
+        # A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64.so.7; loading it
+        # first makes the dynamic linker satisfy this library's libamdhip64.so.7 dependency with the same
+        # copy, so torch tensors and these kernels share one runtime, one device context, one stream space.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(LIB_PATH)
+        vp, sz, i32, u32, u64, f64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint64, C.c_double
+        psz = C.POINTER(C.c_size_t)
+        lib.slam_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.slam_ctx_destroy.argtypes = [vp]
+        lib.slam_set_stream.argtypes = [vp, vp]
+        lib.slam_sync.argtypes = [vp]
+        lib.slam_last_error.argtypes = [vp]
+        lib.slam_last_error.restype = C.c_char_p
+        lib.slam_version.restype = C.c_char_p
+        lib.slam_hex_unpack.argtypes = [vp, vp, sz, vp, sz, psz]
+        lib.slam_parse_records.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
+        lib.slam_parse_text.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
+        lib.slam_correct.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp, vp, C.c_int64,
+                                     vp, vp, vp, vp, psz, vp, vp, vp, vp, vp, psz, psz]
+        lib.slam_pivot_mean.argtypes = [vp, vp, vp, vp, sz, vp, C.c_int, vp, vp, vp]
+        lib.slam_blur_nan.argtypes = [vp, vp, C.c_int, C.c_int, f64, vp]
+        lib.slam_render.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, f64, f64, vp, vp, vp,
+                                    C.c_int, C.c_int, vp]
+        lib.slam_process_frames_dev.argtypes = [vp, C.POINTER(Batch), u32]
+        lib.slam_reserve_workspace.argtypes = [vp, C.POINTER(Batch)]
+        lib.slam_synth_text_len.argtypes = [u32, u32]
+        lib.slam_synth_text_len.restype = sz
+        lib.slam_synth_frames_dev.argtypes = [vp, vp, u64, u32, u32, u32, u32, u64]
+        lib.slam_copy_probe_dev.argtypes = [vp, vp, vp, sz]
+        lib.slam_timing_enable.argtypes = [vp, C.c_int]
+        lib.slam_timing_reset.argtypes = [vp]
+        lib.slam_timing_read.argtypes = [vp, vp, vp, vp, C.c_int]
+        for name in EXPORTS:
+            fn = getattr(lib, name)
+            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len"):
+                fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+class Context:
+    """A slam_ctx bound to one device."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.slam_ctx_create(int(device), C.byref(h))
+        if rc != OK or not h:
+            raise SlamError(rc, f"slam_ctx_create(device={device}) failed: no usable GPU (HIP path has no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int) -> int:
+        if rc < 0:
+            raise SlamError(rc, (self.lib.slam_last_error(self.h) or b"").decode("utf-8", "replace"))
+        return rc
+
+    def set_stream(self, stream_ptr: Optional[int]) -> None:
+        self.check(self.lib.slam_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def sync(self) -> None:
+        self.check(self.lib.slam_sync(self.h))
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.slam_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- timing ------------------------------------------------------------------------------
+    def timing(self, on: bool) -> None:
+        self.check(self.lib.slam_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self) -> None:
+        self.check(self.lib.slam_timing_reset(self.h))
+
+    def timing_read(self):
+        cap = 64
+        names = C.create_string_buffer(32 * cap)
+        launches = (C.c_uint32 * cap)()
+        ms = (C.c_float * cap)()
+        n = self.check(self.lib.slam_timing_read(self.h, names, launches, ms, cap))
+        out = {}
+        for i in range(min(n, cap)):
+            nm = names.raw[32 * i:32 * i + 32].split(b"\0", 1)[0].decode()
+            out[nm] = (int(launches[i]), float(ms[i]))
+        return out
+
+
+_ctxs = {}
+
+
+def ctx(device: int = 0) -> Context:
+    """Process-wide context per device (created on first use)."""
+    c = _ctxs.get(device)
+    if c is None:
+        c = Context(device)
+        _ctxs[device] = c
+    return c
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,160 @@
+"""NumPy-level wrappers of the host-pointer entry points of libslamhip.so.
+
+Each function moves NumPy arrays through one C-ABI call; all arithmetic happens
+in the HIP kernels.  The drop-in modules (serial_hex_to_excel_v3,
+bs_beam_correction, excel_heatmap_v3) are thin layers over these.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ptr
+
+CYCLE, TOL, MOD_BASE = 61000, 500, 64      # bs_beam_correction.py:23-25
+
+
+def _u8(buf) -> np.ndarray:
+    if isinstance(buf, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(buf), dtype=np.uint8)
+    return np.ascontiguousarray(np.asarray(buf), dtype=np.uint8)
+
+
+def hex_unpack(text, device: int = 0) -> np.ndarray:
+    """_read_bytes' data path: raw file bytes -> uint8 array of kept tokens."""
+    c = _lib.ctx(device)
+    t = _u8(text)
+    out = np.empty(len(t) // 2 + 2, np.uint8)
+    n = C.c_size_t(0)
+    c.check(c.lib.slam_hex_unpack(c.h, ptr(t) if len(t) else None, len(t), ptr(out), len(out), C.byref(n)))
+    return out[: n.value].copy()
+
+
+def _parse(fn_name: str, src: np.ndarray, cap: int, device: int):
+    c = _lib.ctx(device)
+    flag = np.empty(cap, np.uint8)
+    ue = np.empty(cap, np.uint8)
+    bs = np.empty(cap, np.uint8)
+    rss = np.empty(cap, np.uint32)
+    clk = np.empty(cap, np.uint32)
+    nv, nd = C.c_size_t(0), C.c_size_t(0)
+    fn = getattr(c.lib, fn_name)
+    c.check(fn(c.h, ptr(src) if len(src) else None, len(src), ptr(flag), ptr(ue), ptr(bs), ptr(rss), ptr(clk),
+               cap, C.byref(nv), C.byref(nd)))
+    v = nv.value
+    return dict(flag=flag[:v], ue=ue[:v], bs=bs[:v], rss=rss[:v], clk=clk[:v]), v, nd.value
+
+
+def parse_records(data, device: int = 0):
+    """_parse_groups' data path: bytes -> (columns dict, valid, discarded)."""
+    b = _u8(data)
+    return _parse("slam_parse_records", b, len(b) // 11 + 2, device)
+
+
+def parse_text(text, device: int = 0):
+    """_read_bytes + _parse_groups fused: raw file bytes -> (columns dict, valid, discarded)."""
+    t = _u8(text)
+    return _parse("slam_parse_text", t, len(t) // 22 + 2, device)
+
+
+def _i32(a, name: str) -> np.ndarray:
+    arr = np.asarray(a)
+    if arr.dtype.kind == "f":
+        if not np.all(np.isfinite(arr)):
+            raise ValueError(f"column {name} holds NaN/inf: not representable on the device")
+        if not np.all(arr == np.round(arr)):
+            raise ValueError(f"column {name} holds non-integers")
+    a64 = arr.astype(np.int64)
+    if a64.size and (a64.min() < -(2 ** 31) or a64.max() >= 2 ** 31):
+        raise ValueError(f"column {name} does not fit int32")
+    return np.ascontiguousarray(a64.astype(np.int32))
+
+
+def correct(flag, ue, bs, rss, clk, cycle: int = CYCLE, tol: int = TOL, mod_base: int = MOD_BASE,
+            baselines: Optional[Sequence[Tuple[int, int]]] = None, device: int = 0):
+    """Correction over a whole table (groups found from UE wraps) or, with `baselines`, over one group.
+
+    Returns dict(kept=(ue, bs, rss, clk) arrays, gid, corrected (-1 = none), baselines=(clk_b, bs_b, gid),
+    n_groups).
+    """
+    c = _lib.ctx(device)
+    f, u, b, r, k = (_i32(x, n) for x, n in ((flag, "FLAG"), (ue, "UE"), (bs, "BS"), (rss, "RSS"), (clk, "CLK")))
+    n = len(f)
+    if not (len(u) == len(b) == len(r) == len(k) == n):
+        raise ValueError("columns differ in length")
+    ou, ob, orr, oc = (np.empty(n, np.int32) for _ in range(4))
+    gid = np.empty(n, np.int32)
+    corr = np.empty(n, np.int32)
+    if baselines is not None:
+        blc_in = _i32([x[0] for x in baselines], "baseline clk")
+        blb_in = _i32([x[1] for x in baselines], "baseline bs")
+        bl_n = len(baselines)
+    else:
+        blc_in = blb_in = None
+        bl_n = -1
+    cap_bl = max(n // 2 + 2, max(bl_n, 0) + 2)
+    blc, blb, blg = (np.empty(cap_bl, np.int32) for _ in range(3))
+    nk, nb, ng = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    c.check(c.lib.slam_correct(c.h, ptr(f), ptr(u), ptr(b), ptr(r), ptr(k), n, int(cycle), int(tol), int(mod_base),
+                               ptr(blc_in), ptr(blb_in), bl_n,
+                               ptr(ou), ptr(ob), ptr(orr), ptr(oc), C.byref(nk), ptr(gid), ptr(corr),
+                               ptr(blc), ptr(blb), ptr(blg), C.byref(nb), C.byref(ng)))
+    kk, bb = nk.value, nb.value
+    return dict(kept=(ou[:kk], ob[:kk], orr[:kk], oc[:kk]), gid=gid, corrected=corr,
+                baselines=(blc[:bb], blb[:bb], blg[:bb]), n_groups=ng.value)
+
+
+def axis_from_mapping(mapping: Dict[int, float]):
+    """BeamID->angle dict -> (beam_to_axis int8[64], sorted distinct angles f64).  Ids outside 0..63 are ignored
+    (excel_heatmap_v3.py:246-247)."""
+    items = [(int(k), float(a)) for k, a in mapping.items() if 0 <= int(k) <= 63 and not math.isnan(float(a))]
+    angles = sorted({a for _, a in items})
+    pos = {a: i for i, a in enumerate(angles)}
+    b2a = np.full(64, -1, np.int8)
+    for k, a in items:
+        b2a[k] = pos[a]
+    return b2a, np.array(angles, np.float64)
+
+
+def pivot_mean(ue, bs, rss, beam_to_axis: np.ndarray, n_axis: int, device: int = 0):
+    """map_angles + compute_rssi_matrix's data path: (sum int64, cnt int64, mean f64) on the full axis grid."""
+    c = _lib.ctx(device)
+    u, b, r = (_i32(x, n) for x, n in ((ue, "ue_beam"), (bs, "bs_beam"), (rss, "rss")))
+    b2a = np.ascontiguousarray(beam_to_axis, dtype=np.int8)
+    s = np.zeros((n_axis, n_axis), np.int64)
+    k = np.zeros((n_axis, n_axis), np.int64)
+    m = np.empty((n_axis, n_axis), np.float64)
+    c.check(c.lib.slam_pivot_mean(c.h, ptr(u), ptr(b), ptr(r), len(u), ptr(b2a), int(n_axis), ptr(s), ptr(k), ptr(m)))
+    return s, k, m
+
+
+def blur_nan(data: np.ndarray, sigma: float, device: int = 0) -> np.ndarray:
+    """gaussian_blur_nan_aware's data path."""
+    c = _lib.ctx(device)
+    a = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.empty_like(a)
+    c.check(c.lib.slam_blur_nan(c.h, ptr(a), a.shape[0], a.shape[1], float(sigma), ptr(out)))
+    return out
+
+
+def render(mat: np.ndarray, aod, aoa, lut: np.ndarray, use_log: bool = False, vmin: Optional[float] = None,
+           vmax: Optional[float] = None, W: int = 1024, H: int = 1024, want_tile: bool = True, device: int = 0):
+    """generate_heatmap's data path after the blur: (cells RGBA [h,w,4], tile RGBA [H,W,4] or None, vmin, vmax)."""
+    c = _lib.ctx(device)
+    m = np.ascontiguousarray(mat, dtype=np.float64)
+    h, w = m.shape
+    ad = np.ascontiguousarray(aod, dtype=np.float64)
+    aa = np.ascontiguousarray(aoa, dtype=np.float64)
+    l = np.ascontiguousarray(lut, dtype=np.uint8).reshape(256, 3)
+    cells = np.empty((h, w, 4), np.uint8)
+    tile = np.empty((H, W, 4), np.uint8) if want_tile else None
+    vv = np.empty(2, np.float64)
+    nan = float("nan")
+    c.check(c.lib.slam_render(c.h, ptr(m), h, w, ptr(ad), ptr(aa), 1 if use_log else 0,
+                              nan if vmin is None else float(vmin), nan if vmax is None else float(vmax),
+                              ptr(l), ptr(cells), ptr(tile), int(W), int(H), ptr(vv)))
+    return cells, tile, float(vv[0]), float(vv[1])

@@ -1,0 +1,322 @@
+"""GPU parity: every C-ABI stage against the CPU oracle and the golden fixtures (run with -m gpu).
+
+Integer / byte outputs must be bit-exact.  Float outputs (mean, blur, limits) are f64 computed in the
+oracle's operation order; the bar written here is 1e-12 relative, far inside the 1e-6 the task states.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import slam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from slamhip import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def mapping():
+    return {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+
+
+@pytest.fixture(scope="module")
+def lut():
+    return np.load(os.path.join(GOLDEN, "viridis_lut.npy"))
+
+
+def _rows_equal(got, exp_rows):
+    exp = np.asarray(exp_rows, np.int64).reshape(-1, 5)
+    for j, k in enumerate(["flag", "ue", "bs", "rss", "clk"]):
+        assert np.array_equal(got[k].astype(np.int64), exp[:, j]), k
+
+
+# ---- a1 / a2 ---------------------------------------------------------------------------------------
+def test_edge_streams_bit_exact(ops):
+    edge = json.load(open(os.path.join(GOLDEN, "edge_streams.json")))
+    for name, e in edge.items():
+        text = bytes(e["text"])
+        by = ops.hex_unpack(text)
+        assert by.tolist() == e["bytes"], f"hex_unpack {name}"
+        rows, v, d = ops.parse_records(np.array(e["bytes"], np.uint8))
+        assert (v, d) == (e["valid"], e["discarded"]), f"parse_records {name}"
+        _rows_equal(rows, e["rows"])
+        rows, v, d = ops.parse_text(text)
+        assert (v, d) == (e["valid"], e["discarded"]), f"parse_text {name}"
+        _rows_equal(rows, e["rows"])
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_truncated_captures_bit_exact(ops, i):
+    z = np.load(os.path.join(GOLDEN, f"log{i}.npz"))
+    by = ops.hex_unpack(z["text"].tobytes())
+    assert np.array_equal(by, z["bytes"])
+    for rows, v, d in (ops.parse_records(z["bytes"]), ops.parse_text(z["text"].tobytes())):
+        assert (v, d) == (int(z["valid"]), int(z["discarded"]))
+        _rows_equal(rows, z["rows"])
+    r = z["rows"]
+    c = ops.correct(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4])
+    assert np.array_equal(c["gid"], z["gid"])
+    assert np.array_equal(np.stack(c["baselines"], 1), z["baselines"])
+    assert np.array_equal(np.stack(c["kept"], 1), z["kept"])
+    corr = np.where(c["corrected"] >= 0, c["corrected"], r[:, 2])
+    assert np.array_equal(corr, z["corrected_inplace"])
+
+
+def test_tokenizer_fuzz_against_oracle(ops):
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b"0123456789abcdefABCDEFxX \t\n\r\x0b\x0c\x1c\x1f\x00gG,-\xc2\x85\xa0\xe2\x80\x82\xa8\xe3\xe1\x9a\xef\xbb\xbf\xf0\x9f\xff\xc0\xed\xf4\x90", np.uint8)
+    for trial in range(40):
+        n = int(rng.integers(1, 6000))
+        t = alphabet[rng.integers(0, len(alphabet), n)].tobytes()
+        exp = O.read_bytes(t)
+        assert np.array_equal(exp, O.read_bytes_py(t))
+        got = ops.hex_unpack(t)
+        assert np.array_equal(got, exp), f"trial {trial}"
+        rows_o, v_o, d_o = O.parse_groups(exp)
+        rows, v, d = ops.parse_text(t)
+        assert (v, d) == (v_o, d_o)
+
+
+def test_framing_fuzz_against_oracle(ops):
+    """Byte soups rich in flag bytes and valid tags, so the scan loses and regains alignment constantly."""
+    rng = np.random.default_rng(11)
+    pool = np.array([0x33, 0xCC, 0x05, 0xC7, 0x41, 0x7F, 0x81, 0xBF, 0x00, 0xFF, 0x33, 0xCC], np.uint8)
+    rec = np.array([0x33, 0x05, 0xC7, 0x41, 0x42, 0x43, 0x44, 0x45, 0x81, 0x82, 0x83], np.uint8)
+    for trial in range(30):
+        parts = []
+        for _ in range(int(rng.integers(1, 400))):
+            if rng.random() < 0.6:
+                r = rec.copy()
+                r[0] = 0xCC if rng.random() < 0.3 else 0x33
+                r[1] = rng.integers(0, 64)
+                r[2] = 0xC0 | rng.integers(0, 64)
+                parts.append(r)
+            else:
+                parts.append(pool[rng.integers(0, len(pool), int(rng.integers(1, 30)))])
+        b = np.concatenate(parts)
+        rows_o, v_o, d_o = O.parse_groups(b)
+        rows, v, d = ops.parse_records(b)
+        assert (v, d) == (v_o, d_o), f"trial {trial} n={len(b)}"
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k]), (trial, k)
+
+
+def test_adversarial_alignment(ops):
+    """Records at two interleaved alignments: no run synchronises, the chained path must agree."""
+    rec2 = bytes([0xCC, 0x33, 0xCC, 0x7F, 0x40, 0x55, 0x6A, 0x41, 0xBF, 0x80, 0x95])
+    for reps in (12, 300, 3000):
+        b = np.frombuffer((rec2[:1] + rec2) * reps, np.uint8)
+        rows_o, v_o, d_o = O.parse_groups(b)
+        rows, v, d = ops.parse_records(b)
+        assert (v, d) == (v_o, d_o)
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k])
+    # every byte a flag byte
+    b = np.full(10000, 0x33, np.uint8)
+    assert ops.parse_records(b)[1:] == O.parse_groups(b)[1:]
+
+
+# ---- a4-a7 -------------------------------------------------------------------------------------------
+def test_unit_tables(ops):
+    ut = json.load(open(os.path.join(GOLDEN, "unit_tables.json")))
+    for name, t in ut.items():
+        r = np.array(t["rows"], np.int64)
+        c = ops.correct(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4])
+        assert c["gid"].tolist() == t["gid"], name
+        assert np.stack(c["baselines"], 1).tolist() == t["baselines"], name
+        assert np.stack(c["kept"], 1).tolist() == t["kept"], name
+        corr = np.where(c["corrected"] >= 0, c["corrected"], r[:, 2])
+        assert corr.tolist() == t["corrected_inplace"], name
+
+
+def test_correct_fuzz_against_oracle(ops):
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        n = int(rng.integers(1, 30000))
+        ue = np.sort(rng.integers(0, 64, n)) if trial % 3 == 0 else (np.arange(n) // max(1, int(rng.integers(1, 200)))) % 64
+        flag = (rng.random(n) < 0.08).astype(np.int64)
+        rss = rng.integers(0, 4, n) if trial % 2 else rng.integers(15000, 93000, n)
+        bs = rng.integers(0, 64, n)
+        cyc = int(rng.choice([61000, 61001, 7, 2, 1000]))
+        tol = int(rng.choice([500, 0, 3, cyc // 2, cyc]))
+        clk = np.cumsum(rng.integers(0, 3 * cyc, n)) % (2 ** 30 - 1)
+        mod = int(rng.choice([64, 10, 255, 1]))
+        kept_o, ng, nb = O.filter_corrected(flag, ue, bs, rss, clk, cyc, tol, mod)
+        c = ops.correct(flag, ue, bs, rss, clk, cyc, tol, mod)
+        assert c["n_groups"] == ng and len(c["baselines"][0]) == nb, trial
+        for a, k in zip(c["kept"], ["ue", "bs", "rss", "clk"]):
+            assert np.array_equal(a.astype(np.int64), kept_o[k]), (trial, k, cyc, tol, mod)
+        ci, wc = O.correct_inplace(flag, ue, bs, rss, clk, cyc, tol, mod)
+        assert np.array_equal(np.where(c["corrected"] >= 0, c["corrected"], bs), ci)
+        assert np.array_equal(c["corrected"] >= 0, wc)
+
+
+def test_correct_large_group_rank_path(ops):
+    """One group with more baselines than the LDS sort holds."""
+    n = 12000
+    flag = np.zeros(n, np.int64)
+    flag[1::2] = 1
+    rss = np.repeat(np.arange(n // 2), 2)
+    ue = np.zeros(n, np.int64)
+    rng = np.random.default_rng(5)
+    clk = np.cumsum(rng.integers(1, 200, n))
+    bs = rng.integers(0, 64, n)
+    kept_o, ng, nb = O.filter_corrected(flag, ue, bs, rss, clk)
+    assert ng == 1 and nb > 2048
+    c = ops.correct(flag, ue, bs, rss, clk)
+    for a, k in zip(c["kept"], ["ue", "bs", "rss", "clk"]):
+        assert np.array_equal(a.astype(np.int64), kept_o[k]), k
+
+
+def test_explicit_baselines(ops):
+    rows = np.array([[0, 0, 10, 21, 2_000_000], [1, 1, 12, 21, 2_000_050], [0, 2, 99, 21, 2_061_020],
+                     [0, 1, 99, 21, 2_061_510]], np.int64)
+    bl = [(2_000_000, 12), (2_000_400, 30), (2_000_400, 31), (1_939_000, 7)]
+    c = ops.correct(*rows.T, baselines=bl)
+    # one group regardless of the UE wrap at the last row; the FLAG=1 row is skipped
+    exp = O.filter_group_py(rows.tolist(), bl)
+    assert len(exp) == 3 and np.stack(c["kept"], 1).tolist() == exp
+    c = ops.correct(*rows.T, baselines=[])
+    assert len(c["kept"][0]) == 0
+
+
+# ---- a9-a13 ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["log0_lin", "log0_log", "log0_noblur", "log0_sigma2", "full_164520", "full_165358"])
+def test_heatmap_stages(ops, mapping, lut, case):
+    z = np.load(os.path.join(GOLDEN, f"heatmap_{case}.npz"))
+    use_log, sigma = bool(z["use_log"]), float(z["sigma"])
+    bl = ops.blur_nan(z["matrix"], sigma)
+    exp = z["blurred"]
+    assert np.array_equal(np.isnan(bl), np.isnan(exp))
+    fin = np.isfinite(exp)
+    assert np.max(np.abs(bl[fin] - exp[fin]) / np.abs(exp[fin])) <= REL
+    ob = O.blur_nan_aware(z["matrix"], sigma)
+    assert np.array_equal(np.isnan(bl), np.isnan(ob))
+    assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL
+    cells, tile, lo, hi = ops.render(bl, z["aod"], z["aoa"], lut, use_log=use_log, W=300, H=200)
+    assert abs(lo - float(z["vmin"])) <= REL * abs(float(z["vmin"])) and abs(hi - float(z["vmax"])) <= REL * abs(float(z["vmax"]))
+    # the scale / colour / raster steps are checked on the SAME blurred matrix, so they must agree exactly
+    r = O.render(bl, z["aod"], z["aoa"], lut, use_log=use_log, blur_sigma=0.0, W=300, H=200)
+    assert (lo, hi) == (r["vmin"], r["vmax"])
+    ocells = r["cells"]
+    diff = (cells.astype(int) != ocells.astype(int)).any(-1)
+    if use_log:      # log10 may differ in the last ulp between libraries: allow one LUT step at bin edges
+        assert diff.mean() < 0.01
+        idx_g = np.abs(cells.astype(int) - ocells.astype(int)).max()
+        assert idx_g <= 12
+    else:
+        assert not diff.any()
+    assert np.array_equal(tile, cells[r_row(r, z, 200)[:, None], r_col(r, z, 300)[None, :]])
+    # and against the reference's own saved PNG: all cells except those under the dashed grid lines
+    cp = z["cells_png"]
+    fin = cells[..., 3] == 255
+    bad = ((cp[..., :3].astype(int) != cells[..., :3].astype(int)).any(-1) & fin).sum()
+    assert bad <= 0.05 * fin.sum()
+
+
+def r_col(r, z, W):
+    return O.raster_index_maps(O.edges(z["aoa"]), O.edges(z["aod"]), W, 8)[0]
+
+
+def r_row(r, z, H):
+    return O.raster_index_maps(O.edges(z["aoa"]), O.edges(z["aod"]), 8, H)[1]
+
+
+def test_pivot_matches_oracle(ops, mapping):
+    z = np.load(os.path.join(GOLDEN, "log0.npz"))
+    k = z["kept"]
+    b2a, angles = ops.axis_from_mapping(mapping)
+    s, c, m = ops.pivot_mean(k[:, 0], k[:, 1], k[:, 2], b2a, len(angles))
+    mat, aod, aoa, so, co = O.pivot_mean(k[:, 0], k[:, 1], k[:, 2], mapping)
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+    rows = np.flatnonzero(c.sum(1) > 0)
+    cols = np.flatnonzero(c.sum(0) > 0)
+    assert np.array_equal(m[np.ix_(rows, cols)], mat, equal_nan=True)
+    hz = np.load(os.path.join(GOLDEN, "heatmap_log0_lin.npz"))
+    assert np.array_equal(m[np.ix_(rows, cols)], hz["matrix"], equal_nan=True)
+    # a sparse mapping with duplicate angles and holes
+    mp = {i: float(i // 2) for i in range(0, 64) if i % 7}
+    b2a, angles = ops.axis_from_mapping(mp)
+    s, c, m = ops.pivot_mean(k[:, 0], k[:, 1], k[:, 2], b2a, len(angles))
+    mat, aod, aoa, so, co = O.pivot_mean(k[:, 0], k[:, 1], k[:, 2], mp)
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+
+
+def test_render_edge_cases(ops, lut):
+    one = np.array([[5.0]])
+    cells, tile, lo, hi = ops.render(one, [1.0], [2.0], lut, W=8, H=4)
+    assert (lo, hi) == (5.0, 5.0) and cells[0, 0].tolist() == [*lut[0], 255] and (tile == cells[0, 0]).all()
+    nanm = np.full((3, 3), np.nan)
+    from slamhip._lib import SlamError, E_ALLNAN
+    with pytest.raises(SlamError) as ei:
+        ops.render(nanm, [1.0, 2.0, 3.0], [1.0, 2.0, 4.0], lut, W=8, H=8)
+    assert ei.value.code == E_ALLNAN
+    m = np.array([[1.0, np.nan], [3.0, 2.0]])
+    cells, tile, lo, hi = ops.render(m, [0.0, 1.0], [0.0, 3.0], lut, vmin=2.0, vmax=2.5, W=16, H=16)
+    r = O.render(m, [0.0, 1.0], [0.0, 3.0], lut, vmin=2.0, vmax=2.5, blur_sigma=0.0, W=16, H=16)
+    assert np.array_equal(cells, r["cells"]) and np.array_equal(tile, r["tile"])
+
+
+# ---- synthetic generator + batched pipeline ----------------------------------------------------------------------
+def test_synth_device_matches_numpy():
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import synth_frames
+    B, N = 8, 256
+    t = synth_frames(3, B, N, first_frame=5)
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    host = t.cpu().numpy()
+    for i in range(3):
+        exp = synth.make_frame_text(B, N, 5 + i)
+        assert len(exp) == tl
+        assert np.array_equal(host[i * stride:i * stride + tl], exp)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 3), (16, 1024, 2), (4, 4096, 2)])
+def test_batched_pipeline_against_oracle(mapping, lut, shape):
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = shape
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N)
+    pipe = FramePipeline(F, tl, tile_w=256, tile_h=128, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    st = pipe.stats_host()
+    for f in range(F):
+        by = synth.make_frame_bytes(B, N, f)
+        assert st[f, 0] == len(by) and st[f, 1] == 0
+        rows_o, v, d = O.parse_groups(by)
+        assert (int(st[f, 2]), int(st[f, 3])) == (v, d)
+        rows = pipe.frame_rows(f, st)
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k]), k
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+        assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"]))
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+        mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
+        full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
+        assert np.array_equal(aod_g, aod) and np.array_equal(aoa_g, aoa)
+        na = len(mapping)
+        assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+        ob = O.blur_nan_aware(mat, 1.0)
+        assert np.array_equal(np.isnan(bl), np.isnan(ob))
+        fin = np.isfinite(ob)
+        assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL
+        r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=128)
+        assert (lo, hi) == (r["vmin"], r["vmax"])
+        assert np.array_equal(pipe.frame_tile(f), r["tile"])
