@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the decode -> correct -> raster hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one batch of F synthetic 256 x 4096 frames (BASELINE.json configs[1]) through
+slam_process_frames_dev: hex text resident in HBM -> decoded records -> corrected rows -> mean matrix ->
+blur -> 1024 x 1024 RGBA tile per frame.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank processes its own frames (weak scaling) and the rendered tiles are gathered to rank 0
+over RCCL on a side stream while the next step computes.
+
+Rank 0 prints ONE JSON line.  `value` is frames/s over all ranks with the text already in HBM when
+the clock starts.  `roofline` prices the dominant kernel (algorithmic bytes / its mean duration from
+HIP events on the launch stream) against the 8 TB/s HBM peak; `cpu_baseline` is the CPU oracle
+(oracle/, a sequential C + NumPy restatement of the reference) timed here on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "slam-process_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--frames-per-step", type=int, default=50)
+    p.add_argument("--beams", type=int, default=256, help="rows (UE sweeps) per frame")
+    p.add_argument("--samples", type=int, default=4096, help="records per row")
+    p.add_argument("--tile", type=int, default=1024)
+    p.add_argument("--distinct-frames", type=int, default=1000, help="frames kept resident in HBM (ring)")
+    p.add_argument("--no-gather", action="store_true", help="N>1: keep tiles on their GPU")
+    p.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle sample (0 = skip)")
+    p.add_argument("--no-kernel-timing", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(B, N, n_frames, mapping, lut, tile):
+    """The CPU oracle on the same synthetic frames, one core."""
+    from oracle import slam_oracle as O
+    from slamhip import synth
+    texts = [synth.make_frame_text(B, N, f).tobytes() for f in range(n_frames)]
+    t0 = time.perf_counter()
+    for t in texts:
+        by = O.read_bytes(t)
+        rows, v, d = O.parse_groups(by)
+        kept, ng, nb = O.filter_corrected(rows["flag"], rows["ue"], rows["bs"], rows["rss"], rows["clk"])
+        mat, aod, aoa, s, c = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"], mapping)
+        O.render(mat, aod, aoa, lut, use_log=False, blur_sigma=1.0, W=tile, H=tile)
+    dt = time.perf_counter() - t0
+    return dict(value=n_frames / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{n_frames} synthetic {B}x{N} frames through oracle/ (sequential C scan + brute-force "
+                       f"baseline search + NumPy blur/raster), {dt:.1f} s on one host core of "
+                       f"{os.cpu_count()} visible")
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from slamhip import _lib, synth
+    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+
+    B, N, F, K, W = a.beams, a.samples, a.frames_per_step, a.steps, a.warmup
+    mapping, lut = default_mapping(), viridis_lut()
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    n_distinct = max(F, min(a.distinct_frames, (K + W) * F))
+    n_distinct = (n_distinct // F) * F
+    # frames of this rank: ids rank*n_distinct .. so every rank works on different data
+    text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=local)
+    gather = world > 1 and not a.no_gather
+    pipe = FramePipeline(F, tl, device=local, tile_w=a.tile, tile_h=a.tile, mapping=mapping, lut=lut,
+                         n_tile_slots=2 * F if gather else F)
+    pipe.set_uniform_layout(F, stride, tl)
+    ctx = pipe.ctx
+    torch.cuda.synchronize(dev)
+
+    comm_stream = torch.cuda.Stream(dev) if gather else None
+    recv = None
+    if gather and rank == 0:
+        recv = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)]
+    pending = []
+
+    def step(i):
+        batch = (i * F) % n_distinct
+        slot = (i % 2) * F if gather else 0
+        pipe.run(text, text_base_offset=batch * stride, tile_slot=slot)
+        if gather:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                src = pipe.tiles[slot:slot + F]
+                dist.gather(src, recv if rank == 0 else None, dst=0)
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            # the slot is reused two steps later: compute must wait for this gather
+            pending.append(done)
+            if len(pending) >= 2:
+                torch.cuda.current_stream(dev).wait_event(pending.pop(0))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize(dev)
+    timing = not a.no_kernel_timing
+    if timing:
+        ctx.timing_reset()
+        ctx.timing(True)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i)
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    kern = {}
+    if timing:
+        ctx.timing(False)
+        kern = ctx.timing_read()
+    dt = t1 - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-frame counts of the last batch for the byte accounting
+    st = pipe.stats_host().astype(np.int64)
+    nbytes = float(st[:, _lib.STAT_NBYTES].mean())
+    valid = float(st[:, _lib.STAT_VALID].mean())
+    kept = float(st[:, _lib.STAT_KEPT].mean())
+    assert int(st[:, _lib.STAT_NOT_STRICT].sum()) == 0
+    records = B * N
+    kappa = kept / max(valid, 1.0)
+    tile_bytes = a.tile * a.tile * 4
+    # algorithmic bytes per frame: read the text (3 per data byte), write decoded records (11 each),
+    # write kept rows (10 each), write the tile
+    alg_frame = 3.0 * nbytes + 11.0 * valid + 10.0 * kept + tile_bytes
+    fps_rank = K * F / dt
+    value = fps_rank * world
+
+    roof = None
+    kern_table = {}
+    if kern:
+        # algorithmic bytes each kernel must move per frame (its own inputs + outputs, no re-reads)
+        alg = {
+            "frame_summarize": 3.0 * nbytes,
+            "frame_emit": 3.0 * nbytes + 11.0 * valid,
+            "rows_summarize": 6.0 * valid,
+            "rows_groups": 6.0 * valid,
+            "rows_correct": 11.0 * valid,
+            "rows_emit_kept": 10.0 * valid + 10.0 * kept,
+            "pivot": 6.0 * kept,
+            "raster": float(tile_bytes),
+        }
+        tot_ms = sum(ms for _, ms in kern.values())
+        for name, (launches, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1]):
+            per = ms / max(launches, 1)
+            ent = dict(launches=launches, avg_ms=round(per, 5), share=round(ms / tot_ms, 4))
+            if name in alg:
+                ent["alg_GBps"] = round(alg[name] * F / (per * 1e-3) / 1e9, 1)
+            kern_table[name] = ent
+        dom = max((n for n in kern if n in alg), key=lambda n: kern[n][1])
+        per = kern[dom][1] / kern[dom][0]
+        ach = alg[dom] * F / (per * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    alg_bytes_per_launch=int(alg[dom] * F), avg_launch_ms=round(per, 5))
+
+    out = {
+        "metric": "frames/s (256-beam x 4096-sample decode+correct+raster)",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"synthetic {B}x{N} hex frames ({records} records, {tl} text bytes each), "
+                               f"{F} frames/step, {n_distinct} distinct frames resident in HBM per GPU, "
+                               f"tile {a.tile}x{a.tile} RGBA",
+                   "frames_per_step": F, "beams": B, "samples": N,
+                   "parallelism": f"frames sharded over {world} GPU(s)" + (", tiles gathered to rank 0 (RCCL)" if gather else "")},
+        "kappa_kept_ratio": round(kappa, 4),
+        "alg_bytes_per_frame": int(alg_frame),
+        "pipeline_alg_GBps": round(fps_rank * alg_frame / 1e9, 1),
+        "pipeline_hbm_frac": round(fps_rank * alg_frame / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": roof,
+        "kernels": kern_table,
+    }
+    if rank == 0:
+        if a.cpu_frames > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(B, N, a.cpu_frames, mapping, lut, a.tile)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

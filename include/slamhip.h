@@ -78,12 +78,15 @@ int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text,
  *   gid_out      group id per input row                                      [n]
  *   corrected    per input row: the corrected BS where a candidate won, else -1   [n]
  *   bl_clk/bl_bs/bl_gid  the baselines found, in order, capacity n/2 + 1
- * If bl_in_n >= 0 the table is treated as ONE group whose baselines are the given
- * bl_in_clk/bl_in_bs (the explicit `baselines` argument of the reference's per-group functions). */
+ * flags & SLAM_CORRECT_ONE_GROUP: the table is ONE group whatever its UE column holds (what the
+ * reference's per-group functions see: their shift(1) never looks at UE).
+ * If bl_in_n >= 0 the table is one group whose baselines are the given bl_in_clk/bl_in_bs (the
+ * explicit `baselines` argument of _correct_group / _filter_group_corrected); none are detected. */
+#define SLAM_CORRECT_ONE_GROUP 1u
 int slam_correct(slam_ctx *ctx,
                  const int32_t *flag, const int32_t *ue, const int32_t *bs,
                  const int32_t *rss, const int32_t *clk, size_t n,
-                 int32_t cycle, int32_t tol, int32_t mod_base,
+                 int32_t cycle, int32_t tol, int32_t mod_base, uint32_t flags,
                  const int32_t *bl_in_clk, const int32_t *bl_in_bs, int64_t bl_in_n,
                  int32_t *out_ue, int32_t *out_bs, int32_t *out_rss, int32_t *out_clk, size_t *n_kept,
                  int32_t *gid_out, int32_t *corrected,

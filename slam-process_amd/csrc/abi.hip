@@ -35,7 +35,7 @@ extern "C" int slam_ctx_create(int device, slam_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SLAM_E_HIP; }
     c->stream = c->own_stream;
     if (hipHostMalloc((void **)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
-        hipStreamDestroy(c->own_stream);
+        (void)hipStreamDestroy(c->own_stream);
         delete c;
         return SLAM_E_HIP;
     }
@@ -46,14 +46,14 @@ extern "C" int slam_ctx_create(int device, slam_ctx **out)
 extern "C" int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_E_INVALID;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    for (auto &p : ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    for (auto e : ctx->ev_pool) hipEventDestroy(e);
-    if (ctx->ws) hipFree(ctx->ws);
-    if (ctx->kern_dev) hipFree(ctx->kern_dev);
-    if (ctx->pinned) hipHostFree(ctx->pinned);
-    hipStreamDestroy(ctx->own_stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->kern_dev) (void)hipFree(ctx->kern_dev);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SLAM_OK;
 }
@@ -143,16 +143,16 @@ int slam_timer_begin(slam_ctx *ctx, const char *name)
         if (!ctx->ev_pool.empty()) { *e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
         else if (hipEventCreate(e) != hipSuccess) return -1;
     }
-    hipEventRecord(p.a, ctx->stream);
+    (void)hipEventRecord(p.a, ctx->stream);
     ctx->pending.push_back(p);
     return (int)ctx->pending.size() - 1;
 }
 
-void slam_timer_end(slam_ctx *ctx, int token) { hipEventRecord(ctx->pending[token].b, ctx->stream); }
+void slam_timer_end(slam_ctx *ctx, int token) { (void)hipEventRecord(ctx->pending[token].b, ctx->stream); }
 
 static void timers_collect(slam_ctx *ctx)
 {
-    hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -400,7 +400,7 @@ extern "C" int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text
 // ------------------------------------------------------------------------------------------------------
 extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *ue, const int32_t *bs,
                             const int32_t *rss, const int32_t *clk, size_t n, int32_t cycle, int32_t tol,
-                            int32_t mod_base, const int32_t *bl_in_clk, const int32_t *bl_in_bs, int64_t bl_in_n,
+                            int32_t mod_base, uint32_t flags, const int32_t *bl_in_clk, const int32_t *bl_in_bs, int64_t bl_in_n,
                             int32_t *out_ue, int32_t *out_bs, int32_t *out_rss, int32_t *out_clk, size_t *n_kept,
                             int32_t *gid_out, int32_t *corrected, int32_t *bl_clk, int32_t *bl_bs, int32_t *bl_gid,
                             size_t *n_baselines, size_t *n_groups)
@@ -452,7 +452,7 @@ extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *u
                                    (int32_t *)(b + oc[3]), (int32_t *)(b + oc[4]), row_cap};
     kept_out_t<int32_t, int32_t> out{(int32_t *)(b + ok[0]), (int32_t *)(b + ok[1]), (int32_t *)(b + ok[2]),
                                      (int32_t *)(b + ok[3])};
-    correct_params prm{cycle, tol, mod_base, explicit_bl ? 1 : 0};
+    correct_params prm{cycle, tol, mod_base, (flags & SLAM_CORRECT_ONE_GROUP) ? 1 : 0, explicit_bl ? 1 : 0};
     SLAM_TRY((correct_rows<int32_t, int32_t>(ctx, in, 1, ws, prm, out, gid_out ? (int32_t *)(b + ogid) : nullptr,
                                              stats)));
     uint32_t st[SLAM_STAT_WORDS];
@@ -649,7 +649,7 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if (stages & 2u) {
         rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
         kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev};
-        correct_params prm{bt->cycle, bt->tol, bt->mod_base, 0};
+        correct_params prm{bt->cycle, bt->tol, bt->mod_base, 0, 0};
         SLAM_TRY((correct_rows<uint8_t, uint32_t>(ctx, in, F, cws, prm, out, nullptr, bt->stats_dev)));
     }
     if (stages & 4u) {

@@ -39,18 +39,20 @@ __device__ __forceinline__ void load4(const T *p, T v[4])
 // boundary / baseline bits of the 4 rows [i0, i0+4) of a frame with n rows
 template <typename T8, typename T32>
 __device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb, uint32_t i0, uint32_t n,
-                                         bool one_group, uint32_t *bound, uint32_t *base)
+                                         int mode, uint32_t *bound, uint32_t *base)
 {
+    // mode bit 0: one group (only row 0 starts a group); bit 1: baselines are given, detect none
     *bound = 0;
     *base = 0;
     if (i0 >= n) return;
-    T8 ue[4], fl[4];
-    T32 rs[4];
-    load4(in.ue + fb + i0, ue);
-    if (one_group) {
+    const bool one_group = mode & 1;
+    if (mode & 2) {
         if (i0 == 0) *bound = 1;
         return;
     }
+    T8 ue[4], fl[4];
+    T32 rs[4];
+    load4(in.ue + fb + i0, ue);
     load4(in.flag + fb + i0, fl);
     load4(in.rss + fb + i0, rs);
     T8 pue = 0, pfl = 0;
@@ -64,7 +66,7 @@ __device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb
     for (int k = 0; k < 4; k++) {
         uint32_t i = i0 + k;
         if (i < n) {
-            bool b = (i == 0) || (pue > ue[k]);
+            bool b = (i == 0) || (!one_group && pue > ue[k]);
             bool bl = !b && fl[k] == 1 && pfl == 0 && rs[k] == prs;
             *bound |= (uint32_t)b << k;
             *base |= (uint32_t)bl << k;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, u
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
     uint32_t bound, base;
-    row_bits(in, (size_t)f * in.row_cap, tile * ROWS_PER_BLOCK + tid * 4, n, one_group != 0, &bound, &base);
+    row_bits(in, (size_t)f * in.row_cap, tile * ROWS_PER_BLOCK + tid * 4, n, one_group, &bound, &base);
     uint32_t cb = wave_sum(__popc(bound)), cl = wave_sum(__popc(base));
     if (lane_id() == 0) { sh[tid >> 6] = cb; sh[4 + (tid >> 6)] = cl; }
     __syncthreads();
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
     if (tile * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
     uint32_t bound, base;
-    row_bits(in, fb, i0, n, one_group != 0, &bound, &base);
+    row_bits(in, fb, i0, n, one_group, &bound, &base);
     uint32_t tot;
     uint32_t packed = __popc(bound) | (__popc(base) << 16);       // both counts fit 16 bits per block
     uint32_t ex = block_excl_scan(packed, sh, &tot);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     if (tile * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
     uint32_t bound, base;
-    row_bits(in, fb, i0, n, one_group != 0, &bound, &base);
+    row_bits(in, fb, i0, n, one_group, &bound, &base);
     uint32_t tot;
     uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
     uint32_t g = rt_gbase[(size_t)f * rt_max + tile] + ex;        // groups started before this thread's rows
@@ -432,11 +434,12 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     const uint32_t rt_max = (in.row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     dim3 grid(rt_max, F), block(256);
     TC *corr = reinterpret_cast<TC *>(ws.corr);
-    const int og = prm.explicit_baselines;
+    const int og = (prm.one_group || prm.explicit_baselines ? 1 : 0) | (prm.explicit_baselines ? 2 : 0);
+    const int keep_bl = prm.explicit_baselines ? 1 : 0;
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
-                (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, og, ws.grp_row, ws.grp_bl, in.row_cap + 1);
+                (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(64, F), dim3(256), ws, in.row_cap, prm.cycle, stats);

@@ -68,7 +68,8 @@ struct correct_ws {
 
 struct correct_params {
     int32_t cycle, tol, mod_base;
-    int explicit_baselines;     // 1: one group, baselines preloaded into bl_clk/bl_bs, count in stats BASELINES
+    int one_group;              // 1: the whole table is one group (UE wraps ignored)
+    int explicit_baselines;     // 1: baselines preloaded into bl_clk/bl_bs, count in stats BASELINES (implies one_group)
 };
 
 template <typename T8, typename T32>

@@ -1,0 +1,347 @@
+"""Drop-in for the reference's excel_heatmap_v3.py: corrected rows -> BS/UE mean-RSSI heatmap PNG.
+
+Same module-level names, arguments, defaults, return types, exceptions and CLI flags as the reference
+script (excel_heatmap_v3.py:36-62 logger, :68-184 main-data reader, :187-258 mapping reader, :264-280
+map_angles, :286-314 compute_rssi_matrix, :320-368 blur, :374-475 generate_heatmap, :481-552 driver,
+:558-646 CLI).  The mean pivot, the NaN-aware blur, the colour scale and the cell colours come from the
+GPU through libslamhip.so; matplotlib only draws the figure furniture (axes, colour bar, title, grid)
+around the device-coloured mesh.  There is no CPU implementation behind the compute functions.
+
+What differs from the reference: workbooks are read with the standard library (no openpyxl); RSS
+values must be integers (the device pivot keeps an exact integer sum per cell); at most 64 distinct
+angles per axis.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import math
+import os
+import sys
+from datetime import datetime
+from typing import Dict, List, Optional, Tuple
+
+import matplotlib
+import matplotlib.pyplot as plt
+import numpy as np
+import pandas as pd
+from matplotlib.cm import ScalarMappable
+from matplotlib.colors import LogNorm, Normalize
+
+from slamhip import ops, xlsx
+
+
+def _setup_chinese_font():
+    for f in ("Microsoft YaHei", "SimHei", "MS Gothic"):
+        try:
+            plt.rcParams["font.sans-serif"] = [f]
+            plt.rcParams["axes.unicode_minus"] = False
+            return
+        except Exception:
+            continue
+    plt.rcParams["axes.unicode_minus"] = False
+
+
+def setup_logger(log_path: str) -> logging.Logger:
+    logger = logging.getLogger("excel_heatmap")
+    logger.setLevel(logging.INFO)
+    if logger.handlers:
+        return logger
+    fmt = logging.Formatter(fmt="%(asctime)s | %(levelname)s | %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+    fh = logging.FileHandler(log_path, encoding="utf-8")
+    fh.setLevel(logging.INFO)
+    fh.setFormatter(fmt)
+    sh = logging.StreamHandler(sys.stdout)
+    sh.setLevel(logging.INFO)
+    sh.setFormatter(fmt)
+    logger.addHandler(fh)
+    logger.addHandler(sh)
+    return logger
+
+
+def validate_beam_id(beam: int) -> bool:
+    return isinstance(beam, (int, np.integer)) and 0 <= int(beam) <= 63
+
+
+def _read_sheets(path: str, sheet_name: Optional[str], what: str):
+    """One DataFrame when a sheet is named, else {sheet: DataFrame} like pd.read_excel(sheet_name=None)."""
+    try:
+        if sheet_name is not None:
+            return pd.DataFrame(xlsx.read_table(path, sheet_name))
+        return {n: pd.DataFrame(t) for n, t in xlsx.read_all_tables(path).items()}
+    except Exception as e:
+        raise RuntimeError(f"读取{what}Excel失败: {e}")
+
+
+def _choose_sheet(df_obj, needed: List[str], sheet_name: Optional[str], logger, label: str) -> pd.DataFrame:
+    if not isinstance(df_obj, dict):
+        if logger and sheet_name is not None:
+            logger.info(f"使用{label}工作表: {sheet_name}")
+        return df_obj
+    chosen = None
+    for name, d in df_obj.items():
+        if all(c in d.columns for c in needed):
+            chosen = name
+            break
+    if chosen is None:
+        chosen = next(iter(df_obj.keys()))
+    if logger:
+        logger.info(f"使用{label}工作表: {chosen}")
+    return df_obj[chosen]
+
+
+def _int_or_nan(x):
+    try:
+        return int(x)
+    except Exception:
+        return np.nan
+
+
+def _float_or_nan(x):
+    try:
+        return float(x)
+    except Exception:
+        return np.nan
+
+
+def read_main_data(input_path: str, ue_col: str = "UE_Beam", bs_col: str = "BS_Beam", rss_col: str = "RSS值",
+                   flag_col: Optional[str] = None, sheet_name: Optional[str] = None,
+                   logger: Optional[logging.Logger] = None) -> pd.DataFrame:
+    """Workbook -> DataFrame(ue_beam, bs_beam, rss[, flag]) of clean rows with beams in 0..63 (reference :75-184)."""
+    if logger:
+        logger.info(f"开始读取主数据文件: {input_path}")
+    if not os.path.exists(input_path):
+        raise FileNotFoundError(f"主数据文件不存在: {input_path}")
+    needed = [ue_col, bs_col, rss_col] + ([flag_col] if flag_col else [])
+    df = _choose_sheet(_read_sheets(input_path, sheet_name, "主数据"), needed, sheet_name, logger, "主数据")
+    for col in needed:
+        if col not in df.columns:
+            raise KeyError(f"主数据缺少必要列: {col}")
+    names = {ue_col: "ue_beam", bs_col: "bs_beam", rss_col: "rss"}
+    if flag_col:
+        names[flag_col] = "flag"
+    df = df[needed].rename(columns=names)
+    df["ue_beam"] = df["ue_beam"].apply(_int_or_nan)
+    df["bs_beam"] = df["bs_beam"].apply(_int_or_nan)
+    if "flag" in df.columns:
+        df["flag"] = df["flag"].apply(_int_or_nan)
+    df["rss"] = df["rss"].apply(_float_or_nan)
+    before = len(df)
+    df = df.dropna(subset=["ue_beam", "bs_beam", "rss"] + (["flag"] if "flag" in df.columns else []))
+    after_dropna = len(df)
+    ok = df["ue_beam"].between(0, 63) & df["bs_beam"].between(0, 63)
+    if "flag" in df.columns:
+        ok &= df["flag"] == 1
+    df = df[ok]
+    if logger:
+        logger.info(f"原始行数: {before}, 去NaN后: {after_dropna}, 过滤FLAG与波束有效后: {len(df)}")
+    if df.empty:
+        raise ValueError("清洗后主数据为空，请检查数据格式是否正确")
+    df = df.copy()
+    df["ue_beam"] = df["ue_beam"].astype(np.int64)
+    df["bs_beam"] = df["bs_beam"].astype(np.int64)
+    return df
+
+
+def read_mapping(map_path: str, id_col: str = "BeamID", angle_col: str = "Angle", sheet_name: Optional[str] = None,
+                 logger: Optional[logging.Logger] = None) -> Dict[int, float]:
+    """Workbook -> {BeamID 0..63: angle in degrees} (reference :187-258)."""
+    if logger:
+        logger.info(f"开始读取映射文件: {map_path}")
+    if not os.path.exists(map_path):
+        raise FileNotFoundError(f"映射文件不存在: {map_path}")
+    df = _choose_sheet(_read_sheets(map_path, sheet_name, "映射"), [id_col, angle_col], sheet_name, logger, "映射")
+    for col in (id_col, angle_col):
+        if col not in df.columns:
+            raise KeyError(f"映射文件缺少必要列: {col}")
+    mapping: Dict[int, float] = {}
+    for bid, ang in zip(df[id_col].tolist(), df[angle_col].tolist()):
+        try:
+            b, a = int(bid), float(ang)
+        except Exception:
+            continue
+        if 0 <= b <= 63:
+            mapping[b] = a
+    if logger:
+        logger.info(f"映射条目数: {len(mapping)} (期望: 64)")
+        missing = [i for i in range(64) if i not in mapping]
+        if missing:
+            logger.warning(f"映射缺失 BeamID: {missing}")
+    if not mapping:
+        raise ValueError("映射数据为空或格式错误")
+    return mapping
+
+
+def map_angles(df: pd.DataFrame, mapping: Dict[int, float], logger: Optional[logging.Logger] = None) -> pd.DataFrame:
+    """Adds AoA (from ue_beam) and AoD (from bs_beam); rows with an unmapped beam go (reference :264-280)."""
+    df = df.copy()
+    df["AoA"] = df["ue_beam"].map(mapping)
+    df["AoD"] = df["bs_beam"].map(mapping)
+    before = len(df)
+    df = df.dropna(subset=["AoA", "AoD"])
+    if logger:
+        logger.info(f"角度映射后有效行数: {len(df)} / {before}")
+    if df.empty:
+        raise ValueError("角度映射后数据为空，可能映射表与数据不一致")
+    return df
+
+
+def compute_rssi_matrix(df: pd.DataFrame, logger: Optional[logging.Logger] = None) -> Tuple[np.ndarray, List[float], List[float]]:
+    """Mean RSS per (AoD, AoA) over the angles that occur, NaN where a pair never occurs (reference :286-314)."""
+    aod_vals = np.unique(df["AoD"].to_numpy(np.float64))
+    aoa_vals = np.unique(df["AoA"].to_numpy(np.float64))
+    if len(aod_vals) > 64 or len(aoa_vals) > 64:
+        raise ValueError("more than 64 distinct angles on an axis: beyond the device pivot's grid")
+    rss = df["rss"].to_numpy(np.float64)
+    if not np.all(rss == np.round(rss)):
+        raise ValueError("non-integer RSS values: the device pivot keeps exact integer sums")
+    r_idx = np.searchsorted(aod_vals, df["AoD"].to_numpy(np.float64))
+    c_idx = np.searchsorted(aoa_vals, df["AoA"].to_numpy(np.float64))
+    n_axis = max(len(aod_vals), len(aoa_vals))
+    ident = np.full(64, -1, np.int8)
+    ident[:n_axis] = np.arange(n_axis)
+    _s, _c, mean = ops.pivot_mean(c_idx, r_idx, rss.astype(np.int64), ident, n_axis)
+    matrix = np.ascontiguousarray(mean[: len(aod_vals), : len(aoa_vals)])
+    if logger:
+        logger.info(f"RSSI矩阵尺寸: {matrix.shape} (AoD: {len(aod_vals)} x AoA: {len(aoa_vals)})")
+    return matrix, aod_vals.tolist(), aoa_vals.tolist()
+
+
+def gaussian_kernel(sigma: float) -> np.ndarray:
+    """Odd-sized normalised Gaussian of about 6 sigma (reference :320-333); [[1.0]] when sigma <= 0."""
+    if sigma <= 0:
+        return np.ones((1, 1), dtype=np.float64)
+    size = max(3, int(math.ceil(6 * sigma)))
+    size += 1 - size % 2
+    r = np.arange(size) - size // 2
+    k = np.exp(-(r[None, :] ** 2 + r[:, None] ** 2) / (2.0 * sigma * sigma))
+    return (k / k.sum()).astype(np.float64)
+
+
+def gaussian_blur_nan_aware(data: np.ndarray, sigma: float) -> np.ndarray:
+    """Normalised convolution that ignores NaN cells, edge padding (reference :336-368)."""
+    if sigma <= 0:
+        return data
+    return ops.blur_nan(np.asarray(data, dtype=np.float64), float(sigma))
+
+
+def _edges(vals: List[float]) -> np.ndarray:
+    v = np.asarray(vals, dtype=np.float64)
+    if len(v) == 1:
+        return np.array([v[0] - 0.5, v[0] + 0.5])
+    mid = (v[:-1] + v[1:]) / 2.0
+    return np.concatenate([[v[0] - (v[1] - v[0]) / 2.0], mid, [v[-1] + (v[-1] - v[-2]) / 2.0]])
+
+
+def _lut_of(colormap: str) -> np.ndarray:
+    """256 x 3 bytes of a matplotlib colormap as the Agg renderer writes them (rounded)."""
+    cmap = plt.get_cmap(colormap)
+    return np.rint(np.asarray(cmap(np.arange(256)))[:, :3] * 255).astype(np.uint8)
+
+
+def generate_heatmap(matrix: np.ndarray, aod_list: List[float], aoa_list: List[float], output_path: str, title: str,
+                     colormap: str = "viridis", use_log: bool = True, vmin: Optional[float] = None,
+                     vmax: Optional[float] = None, blur_sigma: float = 0.0,
+                     logger: Optional[logging.Logger] = None) -> None:
+    """Blur, scale, colour and save the 10 x 8 in figure at dpi 150 (reference :374-475)."""
+    _setup_chinese_font()
+    mat = np.array(matrix, dtype=np.float64, copy=True)
+    if blur_sigma and blur_sigma > 0:
+        if logger:
+            logger.info(f"对矩阵进行高斯模糊，sigma={blur_sigma}")
+        mat = gaussian_blur_nan_aware(mat, blur_sigma)
+    try:
+        cells, _tile, lo, hi = ops.render(mat, aod_list, aoa_list, _lut_of(colormap), use_log=use_log, vmin=vmin,
+                                          vmax=vmax, want_tile=False)
+    except ops._lib.SlamError as e:
+        if e.code == ops._lib.E_ALLNAN:
+            raise ValueError("矩阵数据全为NaN，无法生成热力图")
+        raise
+    fig, ax = plt.subplots(figsize=(10, 8), dpi=120)
+    ax.pcolormesh(_edges(aoa_list), _edges(aod_list), cells.astype(np.float64) / 255.0, shading="flat")
+    norm = LogNorm(vmin=lo, vmax=hi) if use_log else Normalize(vmin=lo, vmax=hi)
+    cbar = fig.colorbar(ScalarMappable(norm=norm, cmap=plt.get_cmap(colormap)), ax=ax)
+    cbar.set_label("RSSI强度" + ("（对数刻度）" if use_log else "（线性刻度）"))
+    ax.set_title(title)
+    ax.set_xlabel("AoA（UE侧，度）")
+    ax.set_ylabel("AoD（BS侧，度）")
+    ax.grid(True, linestyle="--", alpha=0.2)
+    out_dir = os.path.dirname(output_path)
+    if out_dir and not os.path.exists(out_dir):
+        os.makedirs(out_dir, exist_ok=True)
+    plt.tight_layout()
+    plt.savefig(output_path, dpi=150)
+    plt.close(fig)
+    if logger:
+        logger.info(f"热力图已保存: {output_path}")
+
+
+def process_excel_to_heatmap(input_path: str, map_path: str, output_path: Optional[str] = None,
+                             sheet_name_main: Optional[str] = None, sheet_name_map: Optional[str] = None,
+                             colormap: str = "viridis", use_log: bool = True, vmin: Optional[float] = None,
+                             vmax: Optional[float] = None, blur_sigma: float = 0.0,
+                             logger: Optional[logging.Logger] = None) -> str:
+    """read -> validate -> map -> pivot -> draw; returns the PNG path (reference :481-552)."""
+    ts = datetime.now().strftime("%Y%m%d_%H%M%S")
+    log_dir = os.path.dirname(output_path) if output_path else os.path.dirname(input_path)
+    lg = logger or setup_logger(os.path.join(log_dir, f"excel_heatmap_{ts}.log"))
+    try:
+        lg.info("====== 开始处理Excel数据并生成热力图 ======")
+        lg.info(f"主数据文件: {input_path}")
+        lg.info(f"映射文件: {map_path}")
+        df_main = read_main_data(input_path=input_path, sheet_name=sheet_name_main, logger=lg)
+        mapping = read_mapping(map_path=map_path, sheet_name=sheet_name_map, logger=lg)
+        df_mapped = map_angles(df_main, mapping, logger=lg)
+        matrix, aod_list, aoa_list = compute_rssi_matrix(df_mapped, logger=lg)
+        if output_path is None or output_path.strip() == "":
+            base = os.path.splitext(os.path.basename(input_path))[0]
+            output_path = os.path.join(os.path.dirname(input_path), "heatmap_outputs", f"{base}_heatmap.png")
+        title = f"BS-UE 波束对平均RSSI热力图 ({os.path.basename(input_path)})"
+        generate_heatmap(matrix=matrix, aod_list=aod_list, aoa_list=aoa_list, output_path=output_path, title=title,
+                         colormap=colormap, use_log=use_log, vmin=vmin, vmax=vmax, blur_sigma=blur_sigma, logger=lg)
+        lg.info("====== 处理完成 ======")
+        return output_path
+    except Exception as e:
+        lg.error(f"处理失败: {e}", exc_info=True)
+        raise
+
+
+def build_arg_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="读取Excel数据并生成BS-UE平均RSSI热力图（支持中文显示、日志、可选模糊）")
+    p.add_argument("--input", type=str,
+                   default=r"D:\Code\SLAMPro\UE21\debugDoc\Serial Debug 2026-01-26 165358_filtered.xlsx", help="主数据Excel路径")
+    p.add_argument("--mapping", type=str, default=r"D:\桌面\SLAMM\beam_angle.xlsx", help="BeamID->Angle映射Excel路径")
+    p.add_argument("--output", type=str, default="", help="输出PNG路径（默认与主数据同目录的heatmap_outputs下）")
+    p.add_argument("--sheet-main", type=str, default=None, help="主数据工作表名")
+    p.add_argument("--sheet-map", type=str, default=None, help="映射工作表名")
+    p.add_argument("--colormap", type=str, default="viridis", help="热力图风格（如: viridis, plasma, inferno, magma, jet 等）")
+    p.add_argument("--logscale", action="store_true", default=False, help="使用对数颜色标度（默认开启）")
+    p.add_argument("--vmin", type=float, default=None, help="颜色刻度最小RSSI（可选，默认自动）")
+    p.add_argument("--vmax", type=float, default=None, help="颜色刻度最大RSSI（可选，默认自动）")
+    p.add_argument("--blur-sigma", type=float, default=1.0, help="高斯模糊强度（0为不模糊）")
+    return p
+
+
+def main():
+    args = build_arg_parser().parse_args()
+    ts = datetime.now().strftime("%Y%m%d_%H%M%S")
+    log_dir = (os.path.dirname(args.output) if args.output
+               else os.path.dirname(args.input) if os.path.isfile(args.input) else os.getcwd())
+    logger = setup_logger(os.path.join(log_dir, f"excel_heatmap_{ts}.log"))
+    logger.info(f"参数: input='{args.input}', mapping='{args.mapping}', output='{args.output}', "
+                f"sheet_main='{args.sheet_main}', sheet_map='{args.sheet_map}', colormap='{args.colormap}', "
+                f"logscale={args.logscale}, vmin={args.vmin}, vmax={args.vmax}, blur_sigma={args.blur_sigma}")
+    try:
+        out_png = process_excel_to_heatmap(input_path=args.input, map_path=args.mapping,
+                                           output_path=args.output if args.output else None,
+                                           sheet_name_main=args.sheet_main, sheet_name_map=args.sheet_map,
+                                           colormap=args.colormap, use_log=args.logscale, vmin=args.vmin,
+                                           vmax=args.vmax, blur_sigma=args.blur_sigma, logger=logger)
+        logger.info(f"输出PNG: {out_png}")
+    except Exception as e:
+        logger.error(f"执行失败: {e}", exc_info=True)
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

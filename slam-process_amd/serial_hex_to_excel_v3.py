@@ -1,0 +1,102 @@
+"""Drop-in for the reference's serial_hex_to_excel_v3.py: hex capture text -> "Parsed" workbook.
+
+Same module-level names, arguments, return values and CLI as the reference script
+(serial_hex_to_excel_v3.py:18-36 _read_bytes, :41-103 _parse_groups, :105-120 _write_excel,
+:122-158 main); the byte unpack and the resynchronising record scan run on the GPU through
+libslamhip.so.  There is no CPU implementation behind these functions: without the library or a
+GPU they raise.
+
+Differences a caller can see: the workbook is written with the standard library (no openpyxl
+needed), and the per-token / per-reject log lines are summarised (counts and the first rejects'
+positions) instead of one line each.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+from pathlib import Path
+from typing import List, Tuple
+
+from slamhip import ops, xlsx
+
+HEADER = ["FLAG", "UE_Beam[5:0]十进制", "BS_Beam[5:0]十进制", "RSS十进制", "CLK十进制"]   # :110-116
+
+
+def _to_hex(v: int) -> str:
+    return "0x%02X" % v
+
+
+def _top2(v: int) -> int:
+    return (v >> 6) & 3
+
+
+def _lsb6(v: int) -> int:
+    return v & 63
+
+
+def _fmt_bytes(seq: List[int]) -> str:
+    return " ".join(_to_hex(v) for v in seq)
+
+
+def _read_bytes(path: Path, logger: logging.Logger) -> List[int]:
+    """File -> list of byte values, token rules of the reference (:16, :18-36)."""
+    raw = Path(path).read_bytes()
+    data = ops.hex_unpack(raw)
+    logger.debug("hex tokens kept: %d of %d text bytes", len(data), len(raw))
+    return data.tolist()
+
+
+def _parse_groups(bytes_list: List[int], logger: logging.Logger) -> Tuple[List[Tuple[int, int, int, int, int]], int, int]:
+    """Byte values -> (rows of (flag, ue, bs, rss, clk), valid, discarded) (:41-103)."""
+    cols, valid, discarded = ops.parse_records(bytes_list)
+    rows = list(zip(cols["flag"].tolist(), cols["ue"].tolist(), cols["bs"].tolist(),
+                    cols["rss"].tolist(), cols["clk"].tolist()))
+    if discarded:
+        logger.error("丢弃组数=%d (flag bytes whose followers fail the tag checks, or a truncated tail)", discarded)
+    return rows, valid, discarded
+
+
+def parse_file(path: Path, logger: logging.Logger):
+    """Fused fast path: file -> (columns dict of NumPy arrays, valid, discarded) in one device call."""
+    return ops.parse_text(Path(path).read_bytes())
+
+
+def _write_excel(rows, out_path: Path) -> None:
+    """Rows -> workbook with sheet "Parsed" and the reference's five headers (:105-120)."""
+    out_path = Path(out_path)
+    out_path.parent.mkdir(parents=True, exist_ok=True)
+    cols = [list(c) for c in zip(*rows)] if rows else [[] for _ in HEADER]
+    xlsx.write_table(str(out_path), HEADER, cols, sheet="Parsed")
+
+
+def main() -> None:
+    default_in = Path(r"D:\Code\SLAMPro\UE21\debugDoc\Serial Debug 2026-01-27 115303.txt")
+    default_out = Path(r"D:\Code\SLAMPro\UE21\debugDoc\Serial Debug 2026-01-27 115303.xlsx")
+    in_path = Path(sys.argv[1]) if len(sys.argv) >= 2 else default_in
+    out_path = Path(sys.argv[2]) if len(sys.argv) >= 3 else default_out
+    if not in_path.exists():
+        print(f"输入文件不存在: {in_path}")
+        return
+    log_path = out_path.with_suffix(".log")
+    logger = logging.getLogger("serial_hex_to_excel")
+    logger.setLevel(logging.DEBUG)
+    logger.handlers.clear()
+    fh = logging.FileHandler(log_path.as_posix(), mode="w", encoding="utf-8")
+    fh.setFormatter(logging.Formatter("%(asctime)s %(levelname)s %(message)s"))
+    fh.setLevel(logging.DEBUG)
+    sh = logging.StreamHandler()
+    sh.setFormatter(logging.Formatter("%(levelname)s %(message)s"))
+    sh.setLevel(logging.INFO)
+    logger.addHandler(fh)
+    logger.addHandler(sh)
+
+    bytes_list = _read_bytes(in_path, logger)
+    rows, valid, discarded = _parse_groups(bytes_list, logger)
+    _write_excel(rows, out_path)
+    summary = f"有效组数={valid} 丢弃组数={discarded} 输出={out_path} 日志={log_path}"
+    logger.info(summary)
+    print(summary)
+
+
+if __name__ == "__main__":
+    main()

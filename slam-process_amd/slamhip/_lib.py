@@ -89,7 +89,7 @@ def load() -> C.CDLL:
         lib.slam_hex_unpack.argtypes = [vp, vp, sz, vp, sz, psz]
         lib.slam_parse_records.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
         lib.slam_parse_text.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
-        lib.slam_correct.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp, vp, C.c_int64,
+        lib.slam_correct.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, u32, vp, vp, C.c_int64,
                                      vp, vp, vp, vp, psz, vp, vp, vp, vp, vp, psz, psz]
         lib.slam_pivot_mean.argtypes = [vp, vp, vp, vp, sz, vp, C.c_int, vp, vp, vp]
         lib.slam_blur_nan.argtypes = [vp, vp, C.c_int, C.c_int, f64, vp]

@@ -75,8 +75,9 @@ def _i32(a, name: str) -> np.ndarray:
 
 
 def correct(flag, ue, bs, rss, clk, cycle: int = CYCLE, tol: int = TOL, mod_base: int = MOD_BASE,
-            baselines: Optional[Sequence[Tuple[int, int]]] = None, device: int = 0):
-    """Correction over a whole table (groups found from UE wraps) or, with `baselines`, over one group.
+            baselines: Optional[Sequence[Tuple[int, int]]] = None, one_group: bool = False, device: int = 0):
+    """Correction over a whole table (groups found from UE wraps), over the table as ONE group
+    (`one_group`), or over one group with explicit `baselines`.
 
     Returns dict(kept=(ue, bs, rss, clk) arrays, gid, corrected (-1 = none), baselines=(clk_b, bs_b, gid),
     n_groups).
@@ -100,7 +101,7 @@ def correct(flag, ue, bs, rss, clk, cycle: int = CYCLE, tol: int = TOL, mod_base
     blc, blb, blg = (np.empty(cap_bl, np.int32) for _ in range(3))
     nk, nb, ng = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
     c.check(c.lib.slam_correct(c.h, ptr(f), ptr(u), ptr(b), ptr(r), ptr(k), n, int(cycle), int(tol), int(mod_base),
-                               ptr(blc_in), ptr(blb_in), bl_n,
+                               1 if one_group else 0, ptr(blc_in), ptr(blb_in), bl_n,
                                ptr(ou), ptr(ob), ptr(orr), ptr(oc), C.byref(nk), ptr(gid), ptr(corr),
                                ptr(blc), ptr(blb), ptr(blg), C.byref(nb), C.byref(ng)))
     kk, bb = nk.value, nb.value

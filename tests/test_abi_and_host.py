@@ -1,0 +1,173 @@
+"""CPU-side checks: the C-ABI library loads and exports what the header declares; host logic."""
+import hashlib
+import inspect
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PKG, REFERENCE, ROOT, needs_reference
+
+
+def test_library_exports_every_declared_symbol():
+    from slamhip import _lib
+    hdr = open(os.path.join(ROOT, "include", "slamhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.slam_version().startswith(b"slamhip")
+    assert lib.slam_synth_text_len(256, 4096) == 3 + 3 * 256 * (7 + 11 * 4096)
+
+
+def test_batch_struct_matches_the_header():
+    """ctypes mirror of struct slam_batch: same field order as the C declaration."""
+    from slamhip import _lib
+    hdr = open(os.path.join(ROOT, "include", "slamhip.h")).read()
+    body = hdr[hdr.index("typedef struct slam_batch {"):hdr.index("} slam_batch;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    assert names == [f[0] for f in _lib.Batch._fields_]
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from slamhip import _lib, ops
+    with pytest.raises(_lib.SlamError):
+        ops.parse_records(np.zeros(22, np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "slam_oracle" not in src and "liboracle" not in src, os.path.join(dirpath, f)
+
+
+def test_xlsx_round_trip(tmp_path):
+    from slamhip import xlsx
+    p = str(tmp_path / "t.xlsx")
+    xlsx.write_table(p, ["FLAG", "UE_Beam[5:0]十进制", "x<y&z"], [[0, 1, 1], [5, 63, 0], [1.5, None, 2e10]], sheet="Parsed")
+    assert xlsx.sheet_names(p) == ["Parsed"]
+    t = xlsx.read_table(p)
+    assert t["FLAG"] == [0, 1, 1] and t["UE_Beam[5:0]十进制"] == [5, 63, 0] and t["x<y&z"] == [1.5, None, 2e10]
+    import pandas as pd
+    try:
+        import openpyxl  # noqa: F401
+    except ImportError:
+        return
+    assert pd.read_excel(p)["FLAG"].tolist() == [0, 1, 1]
+
+
+@needs_reference
+def test_xlsx_reads_the_reference_workbooks():
+    from slamhip import xlsx
+    t = xlsx.read_table(os.path.join(REFERENCE, "beam_angle.xlsx"))          # shared strings
+    assert t["BeamID"] == list(range(64)) and t["Angle"][0] == -43.6 and t["Angle"][-1] == 45
+    gold = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    assert {i: float(a) for i, a in zip(t["BeamID"], t["Angle"])} == gold
+    t = xlsx.read_table(os.path.join(REFERENCE, "debugDoc", "Serial Debug 2026-02-06 092721.xlsx"))   # inline strings
+    assert len(t["FLAG"]) == 19527
+
+
+def test_synth_generator_is_pinned():
+    from slamhip import synth
+    t = synth.make_frame_text(4, 128, 3)
+    assert len(t) == synth.text_len(4, 128) and bytes(t[:3]) == "« ".encode()
+    assert hashlib.sha256(t.tobytes()).hexdigest() == json.load(open(os.path.join(GOLDEN, "synth_digest.json")))["4x128_f3"]
+    assert not np.array_equal(t, synth.make_frame_text(4, 128, 4))
+    # the generator's frames exercise resync, baselines, ties and drops
+    from oracle import slam_oracle as O
+    by = synth.make_frame_bytes(8, 1024, 0)
+    rows, v, d = O.parse_groups(by)
+    assert 0.99 * 8192 < v < 8192 and d >= 8 * 5
+    kept, ng, nb = O.filter_corrected(rows["flag"], rows["ue"], rows["bs"], rows["rss"], rows["clk"])
+    assert ng == 8 and nb > 8 * 10 and 0.5 < len(kept["ue"]) / v < 0.7
+
+
+@needs_reference
+def test_drop_in_modules_mirror_the_reference_signatures():
+    """Same public names and the same parameter lists as the reference's three scripts."""
+    import importlib.util
+    import matplotlib
+    matplotlib.use("Agg")
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    for mod in ("serial_hex_to_excel_v3", "bs_beam_correction", "excel_heatmap_v3"):
+        ref = load(os.path.join(REFERENCE, mod + ".py"), "ref_" + mod)
+        mine = load(os.path.join(PKG, mod + ".py"), "mine_" + mod)
+        for name, obj in vars(ref).items():
+            if inspect.isfunction(obj) and obj.__module__ == ref.__name__:
+                assert hasattr(mine, name), f"{mod}.{name} missing"
+                ps_ref = [(p.name, p.default) for p in inspect.signature(obj).parameters.values()]
+                ps_mine = [(p.name, p.default) for p in inspect.signature(getattr(mine, name)).parameters.values()]
+                assert ps_ref == ps_mine, f"{mod}.{name}: {ps_ref} != {ps_mine}"
+            elif name.isupper() and isinstance(obj, (int, str)):
+                assert getattr(mine, name) == obj, f"{mod}.{name}"
+
+
+def test_file_balancing_and_sharding():
+    from slamhip import dist as D
+    assert D.shard_frames(10, 1, 4) == [1, 5, 9]
+    sizes = [622083, 3346947, 3348483, 2391555, 2865411, 2639619, 3112707, 2824707, 945411, 1158147]
+    bins = D.balance_files(sizes, 4)
+    assert sorted(i for b in bins for i in b) == list(range(len(sizes)))
+    loads = [sum(sizes[i] for i in b) for b in bins]
+    assert max(loads) - min(loads) <= max(sizes)
+
+
+def test_gather_of_tiles_two_ranks_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): tiles gathered from sharded frames equal the single-rank result."""
+    script = tmp_path / "w.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {PKG!r})
+import torch, torch.distributed as dist
+from slamhip import dist as D
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_frames, H, W = 7, 4, 6
+def tile_of(f):
+    return (torch.arange(H * W * 4, dtype=torch.int64).reshape(H, W, 4) * (f + 3) % 251).to(torch.uint8)
+mine = D.shard_frames(n_frames, rank, world)
+per = (n_frames + world - 1) // world
+tiles = torch.zeros((per, H, W, 4), dtype=torch.uint8)
+for i, f in enumerate(mine):
+    tiles[i] = tile_of(f)
+got = D.gather_tiles(tiles, dst=0)
+if rank == 0:
+    full = D.interleave_gathered(got, n_frames)
+    ref = torch.stack([tile_of(f) for f in range(n_frames)])
+    assert torch.equal(full, ref)
+    open({str(tmp_path / "ok")!r}, "w").write("ok")
+else:
+    assert got is None
+dist.destroy_process_group()
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "ok").exists()

@@ -1,0 +1,156 @@
+"""GPU: the drop-in modules (same call surface as the reference's three scripts) end to end."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import slam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _lg():
+    lg = logging.getLogger("dropin-test")
+    lg.addHandler(logging.NullHandler())
+    lg.propagate = False
+    return lg
+
+
+def test_three_scripts_chain_through_workbooks(tmp_path):
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    import bs_beam_correction as B
+    import excel_heatmap_v3 as E
+    import serial_hex_to_excel_v3 as S
+    from slamhip import xlsx
+    z = np.load(os.path.join(GOLDEN, "log0.npz"))
+    txt = tmp_path / "cap.txt"
+    txt.write_bytes(z["text"].tobytes())
+    # stage 1: same functions main() calls (serial_hex_to_excel_v3.py:153-155)
+    by = S._read_bytes(txt, _lg())
+    assert isinstance(by, list) and by == z["bytes"].tolist()
+    rows, valid, disc = S._parse_groups(by, _lg())
+    assert (valid, disc) == (int(z["valid"]), int(z["discarded"]))
+    assert isinstance(rows[0], tuple) and np.array_equal(np.array(rows), z["rows"])
+    x1 = tmp_path / "cap.xlsx"
+    S._write_excel(rows, x1)
+    assert xlsx.sheet_names(str(x1)) == ["Parsed"]
+    # stage 2
+    out = B.process_excel_filtered(str(x1))
+    assert out == str(tmp_path / "cap_filtered.xlsx")
+    ft = xlsx.read_table(out)
+    assert list(ft.keys()) == ["UE_Beam", "BS_Beam", "RSS值", "CLK值"]
+    assert np.array_equal(np.array([ft[k] for k in ft], np.int64).T, z["kept"])
+    # stage 3
+    mp = tmp_path / "beam_angle.xlsx"
+    m = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    xlsx.write_table(str(mp), ["BeamID", "Angle"], [list(m.keys()), list(m.values())])
+    png = E.process_excel_to_heatmap(out, str(mp), use_log=False, blur_sigma=1.0, logger=_lg())
+    assert png == str(tmp_path / "heatmap_outputs" / "cap_filtered_heatmap.png")
+    from PIL import Image
+    img = np.array(Image.open(png).convert("RGBA"))
+    assert img.shape == (1200, 1500, 4)
+    # the mesh colours in the figure are the device's cell colours: sample the PNG like the fixture did
+    hz = np.load(os.path.join(GOLDEN, "heatmap_log0_lin.npz"))
+    df = E.read_main_data(out)
+    dfm = E.map_angles(df, E.read_mapping(str(mp)))
+    mat, aod, aoa = E.compute_rssi_matrix(dfm)
+    assert np.array_equal(mat, hz["matrix"], equal_nan=True) and aod == hz["aod"].tolist() and aoa == hz["aoa"].tolist()
+    bl = E.gaussian_blur_nan_aware(mat, 1.0)
+    fin = np.isfinite(hz["blurred"])
+    assert np.array_equal(np.isfinite(bl), fin)
+    assert np.max(np.abs(bl[fin] - hz["blurred"][fin]) / np.abs(hz["blurred"][fin])) < 1e-12
+    assert np.allclose(E.gaussian_kernel(1.0), np.load(os.path.join(GOLDEN, "gaussian_kernels.npz"))["s1_0"], rtol=1e-14)
+
+
+def test_bs_beam_correction_functions_and_embedded_suite():
+    import unittest
+    import pandas as pd
+    import bs_beam_correction as B
+    suite = unittest.defaultTestLoader.loadTestsFromTestCase(B.TestBSBeamCorrection)
+    res = unittest.TextTestRunner(verbosity=0).run(suite)
+    assert res.wasSuccessful() and res.testsRun == 5
+    ut = json.load(open(os.path.join(GOLDEN, "unit_tables.json")))
+    t = ut["two_groups_ties"]
+    df = pd.DataFrame(t["rows"], columns=[B.FLAG_COL, B.UE_BEAM_COL, B.BS_BEAM_COL, B.RSS_COL, B.CLK_COL])
+    gid = B._detect_groups(df)
+    assert isinstance(gid, pd.Series) and gid.tolist() == t["gid"]
+    df["_gid"] = gid
+    pieces, bls = [], []
+    for g, sub in df.groupby("_gid", sort=True):
+        bl = B._identify_baselines(sub)
+        bls += [[c, b, int(g)] for c, b in bl]
+        f = B._filter_group_corrected(sub, bl)
+        if not f.empty:
+            pieces.append(f)
+        cg = B._correct_group(sub, bl)
+        assert cg[B.OUT_COL].astype(int).tolist() == [t["corrected_inplace"][i] for i in sub.index]
+    assert bls == t["baselines"]
+    assert pd.concat(pieces, ignore_index=True).to_numpy().tolist() == t["kept"]
+    assert B._choose_correction(B.CYCLE + 40, [(123, 7), (456, 9)]) == 8
+    assert B._choose_correction(B.CYCLE // 2, [(0, 1)]) is None
+    with pytest.raises(ValueError):
+        B._validate_columns(pd.DataFrame({"FLAG": [1]}))
+    with pytest.raises(FileNotFoundError):
+        B.process_excel_filtered("/nonexistent/x.xlsx")
+
+
+def test_errors_follow_the_reference(tmp_path):
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    import excel_heatmap_v3 as E
+    from slamhip import xlsx
+    with pytest.raises(FileNotFoundError):
+        E.read_main_data(str(tmp_path / "none.xlsx"))
+    p = tmp_path / "m.xlsx"
+    xlsx.write_table(str(p), ["UE_Beam", "BS_Beam", "RSS"], [[1], [2], [3]])
+    with pytest.raises(KeyError):
+        E.read_main_data(str(p))                       # default rss_col is "RSS值"
+    with pytest.raises(ValueError):
+        E.map_angles(pd.DataFrame({"ue_beam": [1], "bs_beam": [2], "rss": [3.0]}), {5: 1.0})
+    with pytest.raises(ValueError):
+        E.generate_heatmap(np.full((2, 2), np.nan), [0.0, 1.0], [0.0, 1.0], str(tmp_path / "x.png"), "t", use_log=False)
+
+
+def test_full_size_frames_bit_exact():
+    """BASELINE.json's 256 x 4096 shape, two frames, every integer output against the oracle."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+    B, N, F = 256, 4096, 2
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=41)
+    mapping, lut = default_mapping(), viridis_lut()
+    pipe = FramePipeline(F, tl, tile_w=1024, tile_h=1024, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    st = pipe.stats_host()
+    host = text.cpu().numpy()
+    for f in range(F):
+        t = host[f * stride:f * stride + tl]
+        assert np.array_equal(t, synth.make_frame_text(B, N, 41 + f))
+        by = O.read_bytes(t.tobytes())
+        rows_o, v, d = O.parse_groups(by)
+        assert (int(st[f, 0]), int(st[f, 2]), int(st[f, 3])) == (len(by), v, d)
+        rows = pipe.frame_rows(f, st)
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k]), k
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+        assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"]))
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+        mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
+        full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
+        assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+        r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=1024, H=1024)
+        assert np.array_equal(pipe.frame_tile(f), r["tile"])
+        # size-independent property: the tile holds exactly the colours of the cells
+        tile = pipe.frame_tile(f)
+        assert set(map(tuple, tile.reshape(-1, 4)[::97])) <= set(map(tuple, r["cells"].reshape(-1, 4)))

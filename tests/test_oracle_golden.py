@@ -1,0 +1,134 @@
+"""The CPU oracle against the committed golden fixtures (outputs of the reference's own functions)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import slam_oracle as O
+
+
+@pytest.fixture(scope="module")
+def mapping():
+    return {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+
+
+@pytest.fixture(scope="module")
+def lut():
+    return np.load(os.path.join(GOLDEN, "viridis_lut.npy"))
+
+
+def test_edge_streams():
+    edge = json.load(open(os.path.join(GOLDEN, "edge_streams.json")))
+    assert len(edge) >= 20
+    for name, e in edge.items():
+        text = bytes(e["text"])
+        by = O.read_bytes(text)
+        assert by.tolist() == e["bytes"], name
+        assert O.read_bytes_py(text).tolist() == e["bytes"], name
+        rows, v, d = O.parse_groups(by)
+        assert (v, d) == (e["valid"], e["discarded"]), name
+        got = np.stack([rows[k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1)
+        assert got.tolist() == e["rows"], name
+        rows_py, v2, d2 = O.parse_groups_py(by)
+        assert (v2, d2) == (v, d) and [list(r) for r in rows_py] == e["rows"], name
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_truncated_captures(i):
+    z = np.load(os.path.join(GOLDEN, f"log{i}.npz"))
+    by = O.read_bytes(z["text"].tobytes())
+    assert np.array_equal(by, z["bytes"])
+    rows, v, d = O.parse_groups(by)
+    assert (v, d) == (int(z["valid"]), int(z["discarded"]))
+    r = z["rows"]
+    for j, k in enumerate(("flag", "ue", "bs", "rss", "clk")):
+        assert np.array_equal(rows[k].astype(np.int64), r[:, j])
+    assert np.array_equal(O.detect_groups(r[:, 1]), z["gid"])
+    c, b, g = O.identify_baselines(*r.T)
+    assert np.array_equal(np.stack([c, b, g], 1), z["baselines"])
+    kept, ng, nb = O.filter_corrected(*r.T)
+    assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), z["kept"])
+    ci, _ = O.correct_inplace(*r.T)
+    assert np.array_equal(ci, z["corrected_inplace"])
+
+
+def test_unit_tables_follow_the_code_not_the_failing_test():
+    ut = json.load(open(os.path.join(GOLDEN, "unit_tables.json")))
+    for name, t in ut.items():
+        r = np.array(t["rows"], np.int64)
+        kept, ng, nb = O.filter_corrected(*r.T)
+        assert np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1).tolist() == t["kept"], name
+        assert O.detect_groups(r[:, 1]).tolist() == t["gid"]
+        c, b, g = O.identify_baselines(*r.T)
+        assert np.stack([c, b, g], 1).tolist() == t["baselines"]
+        assert O.correct_inplace(*r.T)[0].tolist() == t["corrected_inplace"]
+    # the reference's test_filter_only_corrected_rows expects 1 row; its code returns 2 (first BS = 12)
+    assert [k[1] for k in ut["filter_only"]["kept"]] == [12, 13]
+
+
+def test_tokenizer_matches_cpython_on_random_bytes():
+    rng = np.random.default_rng(1)
+    alphabet = np.frombuffer(bytes(range(256)) + b"0123456789abcdefABCDEFx  \n\t" * 12, np.uint8)
+    for _ in range(300):
+        t = alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 400)))].tobytes()
+        assert np.array_equal(O.read_bytes(t), O.read_bytes_py(t)), t
+
+
+def test_scan_matches_literal_loop_on_random_bytes():
+    rng = np.random.default_rng(2)
+    pool = np.array([0x33, 0xCC, 0x05, 0xC7, 0x41, 0x7F, 0x81, 0xBF, 0x00, 0xFF], np.uint8)
+    for _ in range(200):
+        b = pool[rng.integers(0, len(pool), int(rng.integers(0, 300)))]
+        rows, v, d = O.parse_groups(b)
+        rp, v2, d2 = O.parse_groups_py(b)
+        assert (v, d) == (v2, d2)
+        got = np.stack([rows[k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1).tolist() if v else []
+        assert got == [list(r) for r in rp]
+
+
+@pytest.mark.parametrize("case", ["log0_lin", "log0_log", "log0_noblur", "log0_sigma2", "full_164520", "full_165358"])
+def test_heatmap_stages(mapping, lut, case):
+    z = np.load(os.path.join(GOLDEN, f"heatmap_{case}.npz"))
+    s, c = z["sum"], z["cnt"]
+    rows = np.flatnonzero(c.sum(1) > 0)
+    cols = np.flatnonzero(c.sum(0) > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mat = np.where(c > 0, s / np.maximum(c, 1), np.nan)[np.ix_(rows, cols)]
+    assert np.array_equal(mat, z["matrix"], equal_nan=True), "mean = exact integer sum / count"
+    ang = np.array([mapping[i] for i in range(64)])
+    assert np.array_equal(ang[rows], z["aod"]) and np.array_equal(ang[cols], z["aoa"])
+    use_log, sigma = bool(z["use_log"]), float(z["sigma"])
+    r = O.render(mat, z["aod"], z["aoa"], lut, use_log=use_log, blur_sigma=sigma, W=64, H=64)
+    bl = z["blurred"]
+    assert np.array_equal(np.isnan(bl), np.isnan(r["blurred"]))
+    fin = np.isfinite(bl)
+    assert np.max(np.abs(bl[fin] - r["blurred"][fin]) / np.abs(bl[fin])) < 1e-12
+    assert abs(r["vmin"] - float(z["vmin"])) <= 1e-12 * abs(float(z["vmin"]))
+    assert abs(r["vmax"] - float(z["vmax"])) <= 1e-12 * abs(float(z["vmax"]))
+    assert np.array_equal(O.edges(z["aoa"]), z["x_edges"]) and np.array_equal(O.edges(z["aod"]), z["y_edges"])
+    # cell colours against the reference's saved PNG sampled at cell centres: everything except the
+    # cells a dashed grid line runs through
+    cp, mine = z["cells_png"], r["cells"]
+    fin = mine[..., 3] == 255
+    bad = ((cp[..., :3].astype(int) != mine[..., :3].astype(int)).any(-1) & fin).sum()
+    assert bad <= 0.05 * fin.sum(), (bad, fin.sum())
+
+
+def test_gaussian_kernels():
+    z = np.load(os.path.join(GOLDEN, "gaussian_kernels.npz"))
+    for key in z.files:
+        sigma = float(key[1:].replace("_", "."))
+        k = O.gaussian_kernel(sigma)
+        assert k.shape == z[key].shape and np.allclose(k, z[key], rtol=1e-14, atol=0)
+
+
+def test_pivot_rows_with_bad_or_unmapped_beams_are_dropped(mapping):
+    ue = np.array([0, 1, 64, -1, 5, 5])
+    bs = np.array([0, 70, 3, 3, 6, 6])
+    rss = np.array([10, 20, 30, 40, 50, 70])
+    mp = {k: v for k, v in mapping.items() if k != 1}
+    mat, aod, aoa, s, c = O.pivot_mean(ue, bs, rss, mp)
+    assert c.sum() == 3 and mat.shape == (2, 2)
+    assert mat[1, 1] == 60.0 and mat[0, 0] == 10.0 and np.isnan(mat[0, 1])

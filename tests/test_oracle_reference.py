@@ -1,0 +1,73 @@
+"""Pins the CPU oracle on the reference itself (build container only: skipped where /root/reference is absent).
+
+1. the reference's own functions, imported, on full captures;
+2. the 19 committed stage outputs debugDoc/<name>.xlsx and <name>_filtered.xlsx (golden vectors).
+"""
+import glob
+import logging
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, needs_reference
+from oracle import slam_oracle as O
+
+pytestmark = needs_reference
+D = os.path.join(REFERENCE, "debugDoc")
+
+
+def _logs():
+    return sorted(glob.glob(os.path.join(D, "*.txt")))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, REFERENCE)
+    import matplotlib
+    matplotlib.use("Agg")
+    import serial_hex_to_excel_v3 as S
+    sys.path.remove(REFERENCE)
+    logging.disable(logging.CRITICAL)
+    yield S
+    logging.disable(logging.NOTSET)
+    for m in ("serial_hex_to_excel_v3",):
+        sys.modules.pop(m, None)
+
+
+def test_all_committed_stage_outputs():
+    from slamhip import xlsx
+    logs = _logs()
+    assert len(logs) == 19
+    for p in logs:
+        raw = open(p, "rb").read()
+        by = O.read_bytes(raw)
+        rows, v, d = O.parse_groups(by)
+        mine = np.stack([rows[k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1)
+        base = os.path.basename(p).replace("256-0x16-", "")[:-4]
+        tab = xlsx.read_table(os.path.join(D, base + ".xlsx"))
+        gold = np.array([tab["FLAG"], tab["UE_Beam[5:0]十进制"], tab["BS_Beam[5:0]十进制"], tab["RSS十进制"],
+                         tab["CLK十进制"]], dtype=np.int64).T
+        off = len(mine) - len(gold)          # 170305.xlsx had its first 9 rows deleted by hand
+        assert off in (0, 9) and np.array_equal(mine[off:], gold), base
+        kept, ng, nb = O.filter_corrected(*mine.T)
+        ft = xlsx.read_table(os.path.join(D, base + "_filtered.xlsx"))
+        rk = [k for k in ft if k.startswith("RSS")][0]
+        gf = np.array([ft["UE_Beam"], ft["BS_Beam"], ft[rk], ft["CLK值"]], dtype=np.int64).T
+        assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), gf), base
+
+
+def test_reference_functions_on_full_captures(ref):
+    from pathlib import Path
+    lg = logging.getLogger("pin")
+    for p in _logs()[:2] + _logs()[-1:]:
+        by_ref = ref._read_bytes(Path(p), lg)
+        by = O.read_bytes(open(p, "rb").read())
+        assert by.tolist() == by_ref
+        rows_ref, v_ref, d_ref = ref._parse_groups(by_ref, lg)
+        rows, v, d = O.parse_groups(by)
+        assert (v, d) == (v_ref, d_ref)
+        arr = np.array(rows_ref, dtype=np.int64)
+        for j, k in enumerate(("flag", "ue", "bs", "rss", "clk")):
+            assert np.array_equal(rows[k].astype(np.int64), arr[:, j])
