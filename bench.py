@@ -43,16 +43,15 @@ def parse_args():
     p.add_argument("--tile", type=int, default=1024)
     p.add_argument("--distinct-frames", type=int, default=1000, help="frames kept resident in HBM (ring)")
     p.add_argument("--no-gather", action="store_true", help="N>1: keep tiles on their GPU")
-    p.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU-oracle sample (0 = skip)")
+    p.add_argument("--cpu-frames", type=int, default=50, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
 
 
-def cpu_baseline(B, N, n_frames, mapping, lut, tile):
-    """The CPU oracle on the same synthetic frames, one core."""
+def cpu_baseline(B, N, texts, mapping, lut, tile):
+    """The CPU oracle on the same synthetic frames (copied back from the device), one core."""
     from oracle import slam_oracle as O
-    from slamhip import synth
-    texts = [synth.make_frame_text(B, N, f).tobytes() for f in range(n_frames)]
+    n_frames = len(texts)
     t0 = time.perf_counter()
     for t in texts:
         by = O.read_bytes(t)
@@ -213,7 +212,9 @@ def main():
     }
     if rank == 0:
         if a.cpu_frames > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(B, N, a.cpu_frames, mapping, lut, a.tile)
+            nf = min(a.cpu_frames, n_distinct)
+            texts = [text[f * stride:f * stride + tl].cpu().numpy().tobytes() for f in range(nf)]
+            out["cpu_baseline"] = cpu_baseline(B, N, texts, mapping, lut, a.tile)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
