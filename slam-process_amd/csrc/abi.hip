@@ -254,9 +254,7 @@ static void one_frame_bind(one_frame &f, uint8_t *b, const size_t off[16], uint3
     f.rows.rss = (uint32_t *)(b + off[7]);
     f.rows.clk = (uint32_t *)(b + off[8]);
     f.rows.row_cap = row_cap;
-    f.fws.summ = (uint32_t *)(b + off[9]);
-    f.fws.tile_entry = b + off[10];
-    f.fws.tile_off = (uint32_t *)(b + off[11]);
+    f.fws.bind(b, off + 9, nt_max);
     f.nt_max = nt_max;
 }
 
@@ -351,7 +349,7 @@ static int parse_common(slam_ctx *ctx, int mode, const uint8_t *src, size_t n_sr
     one_frame_bind(fr, ctx->ws, off, row_cap, nt_max);
     SLAM_TRY(h2d(ctx, fr.src, src, n_src));
     SLAM_TRY(set_one_frame_desc(ctx, fr, (uint32_t)n_src));
-    frame_src fs{fr.src, fr.off, fr.len};
+    frame_src fs{fr.src, fr.off, fr.len, nullptr, 0, nullptr};
     SLAM_TRY(frame_decode(ctx, mode, fs, 1, (uint32_t)n_src, fr.fws, nt_max, fr.rows, fr.stats));
     uint32_t st[SLAM_STAT_WORDS];
     SLAM_TRY(read_stats(ctx, fr.stats, st));
@@ -364,7 +362,7 @@ static int parse_common(slam_ctx *ctx, int mode, const uint8_t *src, size_t n_sr
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t nb = ctx->pinned[0];
         SLAM_TRY(set_one_frame_desc(ctx, fr, nb));
-        frame_src gs{gen, fr.off, fr.len};
+        frame_src gs{gen, fr.off, fr.len, nullptr, 0, nullptr};
         // the strict estimate (n/3 bytes) bounds the general count (n/2 at most -> tiles and rows still fit?)
         const uint32_t nt_gen = frame_tiles_for(SRC_RAW, nb);
         if (nt_gen > nt_max || (uint64_t)nb / 11 + 16 > row_cap)
@@ -452,7 +450,12 @@ extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *u
                                    (int32_t *)(b + oc[3]), (int32_t *)(b + oc[4]), row_cap};
     kept_out_t<int32_t, int32_t> out{(int32_t *)(b + ok[0]), (int32_t *)(b + ok[1]), (int32_t *)(b + ok[2]),
                                      (int32_t *)(b + ok[3])};
-    correct_params prm{cycle, tol, mod_base, (flags & SLAM_CORRECT_ONE_GROUP) ? 1 : 0, explicit_bl ? 1 : 0};
+    correct_params prm;
+    prm.set_cycle(cycle);
+    prm.tol = tol;
+    prm.mod_base = mod_base;
+    prm.one_group = (flags & SLAM_CORRECT_ONE_GROUP) ? 1 : 0;
+    prm.explicit_baselines = explicit_bl ? 1 : 0;
     SLAM_TRY((correct_rows<int32_t, int32_t>(ctx, in, 1, ws, prm, out, gid_out ? (int32_t *)(b + ogid) : nullptr,
                                              stats)));
     uint32_t st[SLAM_STAT_WORDS];
@@ -585,7 +588,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[3], cw[16], rw[5];
+    size_t fw[4], cw[16], rw[5];
     uint32_t nt_max, bl_cap;
     size_t total;
 };
@@ -634,7 +637,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: render stage needs the axis table, LUT and tile size");
     SLAM_TRY(slam_ws_reserve(ctx, bp.total));
     uint8_t *b = ctx->ws;
-    frame_ws fws{(uint32_t *)(b + bp.fw[0]), b + bp.fw[1], (uint32_t *)(b + bp.fw[2])};
+    frame_ws fws;
+    fws.bind(b, bp.fw, bp.nt_max);
     correct_ws cws;
     cws.bind(b, bp.cw, bp.bl_cap);
     render_ws rws;
@@ -642,14 +646,18 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
     if (stages & 1u) {
         SLAM_HIP(ctx, hipMemsetAsync(bt->stats_dev, 0, (size_t)F * SLAM_STAT_WORDS * 4, ctx->stream));
-        frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev};
+        frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev, nullptr, 0, nullptr};
         SLAM_TRY(frame_decode(ctx, bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, fs, F, bt->max_text_len, fws, bp.nt_max,
                               rows, bt->stats_dev));
     }
     if (stages & 2u) {
         rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
         kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev};
-        correct_params prm{bt->cycle, bt->tol, bt->mod_base, 0, 0};
+        if (bt->cycle <= 0 || bt->cycle > (1 << 30)) return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");
+        correct_params prm;
+        prm.set_cycle(bt->cycle);
+        prm.tol = bt->tol;
+        prm.mod_base = bt->mod_base;
         SLAM_TRY((correct_rows<uint8_t, uint32_t>(ctx, in, F, cws, prm, out, nullptr, bt->stats_dev)));
     }
     if (stages & 4u) {

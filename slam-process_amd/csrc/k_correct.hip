@@ -173,8 +173,22 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
     }
 }
 
+// floor(n / cycle) and n mod cycle for n = clk + bias >= 0 (bias is a multiple of cycle, so quotient
+// differences and remainders are those of clk itself).  Division by the launch-constant cycle is a
+// multiply-high with a host-computed magic number (exact for every 32-bit n).
+__device__ __forceinline__ void phase_of(int32_t clk, const correct_params &p, uint32_t *q, uint32_t *r)
+{
+    const uint32_t n = (uint32_t)clk + p.bias;
+    const uint32_t hi = __umulhi(p.div_m, n);
+    const uint32_t qq = (hi + ((n - hi) >> p.div_s1)) >> p.div_s2;
+    *q = qq;
+    *r = n - qq * (uint32_t)p.cycle;
+}
+
 // Per group: sort baseline phases (clk_b mod cycle), keep the earliest baseline of each phase.
-__global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap, int32_t cycle,
+// Output per distinct phase, ascending: srt_rb = phase, srt_pay = (baseline index in its group,
+// clk_b div cycle, bs_b, 0).
+__global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap, correct_params prm,
                                                   const uint32_t *stats)
 {
     __shared__ unsigned long long keys[SORT_CAP];
@@ -193,9 +207,15 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
         if (m <= SORT_CAP) {
             uint32_t P = 1;
             while (P < m) P <<= 1;
-            for (uint32_t i = tid; i < P; i += 256)
-                keys[i] = i < m ? ((unsigned long long)(uint32_t)pymod(ws.bl_clk[bsb + b0 + i], cycle) << 32) | i
-                                : ~0ull;
+            for (uint32_t i = tid; i < P; i += 256) {
+                unsigned long long key = ~0ull;
+                if (i < m) {
+                    uint32_t q, r;
+                    phase_of(ws.bl_clk[bsb + b0 + i], prm, &q, &r);
+                    key = ((unsigned long long)r << 32) | i;
+                }
+                keys[i] = key;
+            }
             __syncthreads();
             for (uint32_t k = 2; k <= P; k <<= 1) {
                 for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -222,11 +242,10 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
                 uint32_t tot;
                 uint32_t ex = block_excl_scan(keep ? 1u : 0u, sh, &tot);
                 if (keep) {
-                    uint32_t o = run + ex, idx = (uint32_t)key;
-                    ws.srt_rb[bsb + b0 + o] = (uint32_t)(key >> 32);
-                    ws.srt_idx[bsb + b0 + o] = idx;
-                    ws.srt_clk[bsb + b0 + o] = ws.bl_clk[bsb + b0 + idx];
-                    ws.srt_bs[bsb + b0 + o] = ws.bl_bs[bsb + b0 + idx];
+                    uint32_t o = run + ex, idx = (uint32_t)key, q, r;
+                    phase_of(ws.bl_clk[bsb + b0 + idx], prm, &q, &r);
+                    ws.srt_rb[bsb + b0 + o] = r;
+                    ws.srt_pay[bsb + b0 + o] = make_uint4(idx, q, (uint32_t)ws.bl_bs[bsb + b0 + idx], 0);
                 }
                 run += tot;
             }
@@ -236,7 +255,11 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
             // rank path: a phase is kept when no earlier baseline has it; its position is the number
             // of kept phases below it.  O(m^2) per group, for groups too large for the LDS sort.
             uint32_t *tmp_rb = ws.tmp_a + bsb + b0, *tmp_keep = ws.tmp_b + bsb + b0;
-            for (uint32_t i = tid; i < m; i += 256) tmp_rb[i] = (uint32_t)pymod(ws.bl_clk[bsb + b0 + i], cycle);
+            for (uint32_t i = tid; i < m; i += 256) {
+                uint32_t q, r;
+                phase_of(ws.bl_clk[bsb + b0 + i], prm, &q, &r);
+                tmp_rb[i] = r;
+            }
             __syncthreads();
             for (uint32_t i = tid; i < m; i += 256) {
                 uint32_t rb = tmp_rb[i], keep = 1;
@@ -248,12 +271,11 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
             uint32_t kept_total = 0;
             for (uint32_t i = tid; i < m; i += 256) {
                 if (!tmp_keep[i]) continue;
-                uint32_t rb = tmp_rb[i], pos = 0;
-                for (uint32_t q = 0; q < m; q++) pos += (tmp_keep[q] && tmp_rb[q] < rb) ? 1u : 0u;
+                uint32_t rb = tmp_rb[i], pos = 0, q, r;
+                for (uint32_t z = 0; z < m; z++) pos += (tmp_keep[z] && tmp_rb[z] < rb) ? 1u : 0u;
+                phase_of(ws.bl_clk[bsb + b0 + i], prm, &q, &r);
                 ws.srt_rb[bsb + b0 + pos] = rb;
-                ws.srt_idx[bsb + b0 + pos] = i;
-                ws.srt_clk[bsb + b0 + pos] = ws.bl_clk[bsb + b0 + i];
-                ws.srt_bs[bsb + b0 + pos] = ws.bl_bs[bsb + b0 + i];
+                ws.srt_pay[bsb + b0 + pos] = make_uint4(i, q, (uint32_t)ws.bl_bs[bsb + b0 + i], 0);
                 kept_total++;
             }
             uint32_t tot;
@@ -270,6 +292,44 @@ struct corr_none<uint8_t> { static constexpr uint8_t v = 0xFF; };
 template <>
 struct corr_none<int32_t> { static constexpr int32_t v = -1; };
 
+constexpr int TAB_CAP = 1024;         // phases of one group staged in LDS by k_rows_correct
+constexpr uint32_t TAB_MAX_GROUPS = 16; // tiles spanning more groups than this search the tables in global memory
+
+// Nearest phase of (q1, r) in a group's table rb[0..nd) / pay[0..nd): returns true and the corrected BS.
+template <typename RB, typename PAY>
+__device__ __forceinline__ bool best_phase(const RB *rb, const PAY *pay, uint32_t nd, uint32_t q1, uint32_t r,
+                                           const correct_params &prm, int32_t *out_bs)
+{
+    uint32_t lo = 0, hi = nd;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rb[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t is = lo < nd ? lo : 0, ip = lo > 0 ? lo - 1 : nd - 1;      // circular successor / predecessor
+    const uint32_t vs = rb[is], vp = rb[ip];
+    const uint32_t cyc = (uint32_t)prm.cycle;
+    const uint32_t xs = vs > r ? vs - r : r - vs, xp = vp > r ? vp - r : r - vp;
+    const uint32_t rs_ = min(xs, cyc - xs), rp_ = min(xp, cyc - xp);
+    uint4 ws_ = pay[is];
+    uint32_t resid = rs_, vw = vs;
+    if (rp_ <= rs_) {
+        const uint4 wp = pay[ip];
+        if (rp_ < rs_ || wp.x < ws_.x) { ws_ = wp; resid = rp_; vw = vp; }      // ties: the earlier baseline
+    }
+    if ((int64_t)resid > (int64_t)prm.tol) return false;
+    // d = clk - clk_b = Q*cycle + x with |x| < cycle; k = round-half-even(d / cycle)
+    const int32_t Q = (int32_t)(q1 - ws_.y);
+    const int32_t x = (int32_t)r - (int32_t)vw;
+    const uint32_t ax2 = 2u * (uint32_t)(x < 0 ? -x : x);
+    int32_t k;
+    if (ax2 < cyc) k = Q;
+    else if (ax2 > cyc) k = x > 0 ? Q + 1 : Q - 1;
+    else { const int32_t base = x > 0 ? Q : Q - 1; k = (base & 1) ? base + 1 : base; }
+    const int32_t v = (int32_t)ws_.z + k;
+    *out_bs = (prm.mod_base & (prm.mod_base - 1)) == 0 ? (v & (prm.mod_base - 1)) : pymod(v, prm.mod_base);
+    return true;
+}
+
 // Per row: nearest baseline phase of its group -> corrected BS or "none"; kept count per tile.
 template <typename T8, typename T32, typename TC>
 __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
@@ -278,6 +338,9 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
                                                        const uint32_t *stats)
 {
     __shared__ uint32_t sh[17];
+    __shared__ uint32_t t_rb[TAB_CAP];
+    __shared__ uint4 t_pay[TAB_CAP];
+    __shared__ uint32_t shk[4];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
@@ -286,58 +349,74 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     uint32_t bound, base;
     row_bits(in, fb, i0, n, one_group, &bound, &base);
     uint32_t tot;
-    uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
-    uint32_t g = rt_gbase[(size_t)f * rt_max + tile] + ex;        // groups started before this thread's rows
+    const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+    const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
     const size_t gs = (size_t)f * (in.row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
-    uint32_t kept = 0;
+    // groups this tile touches: the one running into it (gbase - 1) and those starting in it
+    const uint32_t glo = gbase ? gbase - 1 : 0, ghi = gbase + tot - 1;
+    T8 fl[4] = {1, 1, 1, 1};
+    T32 ck[4] = {0, 0, 0, 0};
+    uint32_t gi[4], q1[4], r1[4];
+    TC res[4];
     if (i0 < n) {
-        T8 fl[4];
-        T32 ck[4];
         load4(in.flag + fb + i0, fl);
         load4(in.clk + fb + i0, ck);
-        TC res[4];
+    }
+    {
+        uint32_t g = gbase + ex;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            res[k] = corr_none<TC>::v;
-            uint32_t i = i0 + k;
-            if (i >= n) continue;
             if ((bound >> k) & 1u) g++;
-            if (fl[k] == 1) continue;
-            const uint32_t gi = g - 1;
-            const uint32_t nd = ws.grp_nd[gs + gi];
-            if (nd == 0) continue;
-            const uint32_t *rb = ws.srt_rb + bsb + ws.grp_bl[gs + gi];
-            const int32_t clk = (int32_t)ck[k];
-            const uint32_t r = (uint32_t)pymod(clk, prm.cycle);
-            uint32_t lo = 0, hi = nd;
-            while (lo < hi) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (rb[mid] < r) lo = mid + 1; else hi = mid;
-            }
-            uint32_t is = lo < nd ? lo : 0, ip = lo > 0 ? lo - 1 : nd - 1;
-            uint32_t vs = rb[is], vp = rb[ip];
-            uint32_t xs = vs > r ? vs - r : r - vs, xp = vp > r ? vp - r : r - vp;
-            uint32_t rs_ = min(xs, (uint32_t)prm.cycle - xs), rp_ = min(xp, (uint32_t)prm.cycle - xp);
-            const uint32_t *sidx = ws.srt_idx + bsb + ws.grp_bl[gs + gi];
-            uint32_t w = is, resid = rs_;
-            if (rp_ < rs_ || (rp_ == rs_ && sidx[ip] < sidx[is])) { w = ip; resid = rp_; }
-            if ((int64_t)resid > (int64_t)prm.tol) continue;
-            const size_t wi = bsb + ws.grp_bl[gs + gi] + w;
-            int32_t d = clk - ws.srt_clk[wi];
-            int32_t q = d / prm.cycle, rem = d - q * prm.cycle;
-            if (rem < 0) { rem += prm.cycle; q--; }
-            int64_t twice = 2ll * rem;
-            int32_t kk = twice > prm.cycle ? q + 1 : (twice < prm.cycle ? q : ((q & 1) ? q + 1 : q));
-            res[k] = (TC)pymod(ws.srt_bs[wi] + kk, prm.mod_base);
-            kept++;
+            gi[k] = g - 1;
+            res[k] = corr_none<TC>::v;
+            if (i0 + k >= n) fl[k] = 1;                       // rows past the end take no part
+            phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
         }
+    }
+    uint32_t kept = 0;
+    const bool staged = (ghi - glo) < TAB_MAX_GROUPS;
+    if (staged) {
+        for (uint32_t gg = glo; gg <= ghi; gg++) {
+            const uint32_t nd = ws.grp_nd[gs + gg];
+            if (nd == 0) continue;                              // block-uniform
+            const uint32_t *grb = ws.srt_rb + bsb + ws.grp_bl[gs + gg];
+            const uint4 *gpay = ws.srt_pay + bsb + ws.grp_bl[gs + gg];
+            const bool in_lds = nd <= TAB_CAP;
+            if (in_lds) {
+                for (uint32_t i = tid; i < nd; i += 256) { t_rb[i] = grb[i]; t_pay[i] = gpay[i]; }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (fl[k] == 1 || gi[k] != gg) continue;
+                int32_t bsn;
+                const bool hit = in_lds ? best_phase(t_rb, t_pay, nd, q1[k], r1[k], prm, &bsn)
+                                        : best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn);
+                if (hit) { res[k] = (TC)bsn; kept++; }
+            }
+            if (in_lds) __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (fl[k] == 1) continue;
+            const uint32_t nd = ws.grp_nd[gs + gi[k]];
+            if (nd == 0) continue;
+            int32_t bsn;
+            if (best_phase(ws.srt_rb + bsb + ws.grp_bl[gs + gi[k]], ws.srt_pay + bsb + ws.grp_bl[gs + gi[k]], nd,
+                           q1[k], r1[k], prm, &bsn)) {
+                res[k] = (TC)bsn;
+                kept++;
+            }
+        }
+    }
+    if (i0 < n) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (i0 + k < n) corr[fb + i0 + k] = res[k];
     }
-    uint32_t c = wave_sum(kept);
-    __shared__ uint32_t shk[4];
+    const uint32_t c = wave_sum(kept);
     if (lane_id() == 0) shk[tid >> 6] = c;
     __syncthreads();
     if (tid == 0) rt_nkept[(size_t)f * rt_max + tile] = shk[0] + shk[1] + shk[2] + shk[3];
@@ -392,10 +471,11 @@ void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap,
     off[3] = p.add((size_t)F * (row_cap + 1) * 4);
     off[4] = p.add((size_t)F * (row_cap + 1) * 4);
     off[5] = p.add((size_t)F * (row_cap + 1) * 4);
-    for (int i = 6; i < 13; i++) off[i] = p.add((size_t)F * bl_cap * 4);
-    off[13] = p.add((size_t)F * row_cap * 4);
-    off[14] = p.add((size_t)F * bl_cap * 4);
-    off[15] = p.add((size_t)F * bl_cap * 4);
+    for (int i = 6; i < 10; i++) off[i] = p.add((size_t)F * bl_cap * 4);
+    off[10] = p.add((size_t)F * bl_cap * 16);
+    off[11] = p.add((size_t)F * row_cap * 4);
+    off[12] = p.add((size_t)F * bl_cap * 4);
+    off[13] = p.add((size_t)F * bl_cap * 4);
 }
 
 void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
@@ -410,13 +490,24 @@ void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
     bl_bs = (int32_t *)(base + off[7]);
     bl_gid = (uint32_t *)(base + off[8]);
     srt_rb = (uint32_t *)(base + off[9]);
-    srt_clk = (int32_t *)(base + off[10]);
-    srt_bs = (int32_t *)(base + off[11]);
-    srt_idx = (uint32_t *)(base + off[12]);
-    corr = (int32_t *)(base + off[13]);
-    tmp_a = (uint32_t *)(base + off[14]);
-    tmp_b = (uint32_t *)(base + off[15]);
+    srt_pay = (uint4 *)(base + off[10]);
+    corr = (int32_t *)(base + off[11]);
+    tmp_a = (uint32_t *)(base + off[12]);
+    tmp_b = (uint32_t *)(base + off[13]);
     bl_cap = bl_cap_;
+}
+
+// magic number for unsigned division by d (1 <= d <= 2^30): q = (hi + ((n - hi) >> s1)) >> s2, hi = mulhi(m, n)
+void correct_params::set_cycle(int32_t c)
+{
+    cycle = c;
+    const uint32_t d = (uint32_t)c;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    div_m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d) + 1;
+    div_s1 = l < 1 ? l : 1;
+    div_s2 = l > 0 ? l - 1 : 0;
+    bias = d * (uint32_t)((((uint64_t)1 << 30) + d - 1) / d);
 }
 
 template <typename T8, typename T32>
@@ -425,8 +516,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
 {
     using TC = typename std::conditional<sizeof(T8) == 1, uint8_t, int32_t>::type;
     if (F == 0) return SLAM_OK;
-    if (prm.cycle <= 0 || prm.mod_base <= 0)
-        return slam_fail(ctx, SLAM_E_INVALID, "cycle and mod_base must be positive");
+    if (prm.cycle <= 0 || prm.cycle > (1 << 30) || prm.mod_base <= 0 || prm.div_m == 0)
+        return slam_fail(ctx, SLAM_E_INVALID, "cycle must be in 1..2^30 (set through set_cycle) and mod_base positive");
     if (sizeof(T8) == 1 && prm.mod_base > 255)
         return slam_fail(ctx, SLAM_E_RANGE, "mod_base > 255 does not fit the 8-bit beam columns");
     if (in.row_cap % 16)
@@ -442,7 +533,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                 (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
-    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(64, F), dim3(256), ws, in.row_cap, prm.cycle, stats);
+    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(64, F), dim3(256), ws, in.row_cap, prm, stats);
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
                 corr, prm, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,

@@ -25,7 +25,7 @@ struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t v[2]; };
 
 struct src_view {
-    const uint8_t *p;     // first token character (SRC_TEXT3) or first data byte (SRC_RAW)
+    const uint8_t *p;     // first token character (SRC_TEXT3) or first data byte (SRC_RAW / SRC_DEC)
     uint32_t n_src;       // source bytes from p
     uint32_t nb;          // data bytes
     bool bad;             // text length cannot be a whole number of "XX " tokens
@@ -35,9 +35,15 @@ template <int MODE>
 __device__ __forceinline__ src_view resolve_src(const frame_src &s, uint32_t f)
 {
     src_view v;
+    v.bad = false;
+    if (MODE == SRC_DEC) {                 // bytes decoded by pass 1 of this launch sequence
+        v.p = s.dec + (size_t)f * s.dec_stride;
+        v.nb = s.stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES];
+        v.n_src = v.nb;
+        return v;
+    }
     const uint8_t *p = s.base + s.off[f];
     uint32_t n = s.len[f];
-    v.bad = false;
     if (MODE == SRC_TEXT3) {
         uint32_t pre = 0;
         if (n >= 3 && p[0] == 0xC2 && p[1] == 0xAB && p[2] == 0x20) pre = 3;   // leading "« "
@@ -77,30 +83,39 @@ __device__ __forceinline__ int hexval(uint32_t c)
     return -1;
 }
 
+// 12 text bytes "HL HL HL HL " (t0 = bytes 0..3, t1 = 4..7, t2 = 8..11) -> 4 data bytes.
+// v_perm gathers the four high-nibble characters, the four low-nibble characters and the four
+// separators into one dword each; nibble values and the format check are then 4-wide SWAR.
+template <bool VALIDATE>
+__device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t t2, bool *not_strict)
+{
+    const uint32_t ha = __builtin_amdgcn_perm(t1, t0, 0x0C060300u);
+    const uint32_t h = __builtin_amdgcn_perm(t2, ha, 0x05020100u);
+    const uint32_t la = __builtin_amdgcn_perm(t1, t0, 0x0C070401u);
+    const uint32_t l = __builtin_amdgcn_perm(t2, la, 0x06020100u);
+    if (VALIDATE) {
+        const uint32_t sa = __builtin_amdgcn_perm(t1, t0, 0x0C0C0502u);
+        const uint32_t sp = __builtin_amdgcn_perm(t2, sa, 0x07040100u);
+        if (not_hex4(h) | not_hex4(l) | (sp ^ 0x20202020u)) *not_strict = true;
+    }
+    return (nib4(h) << 4) | nib4(l);
+}
+
 // One dword (4 data bytes starting at data index gb) of a frame; zero beyond the end.
-template <int MODE>
+template <int MODE, bool VALIDATE>
 __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t gb, bool *not_strict)
 {
     if (gb >= sv.nb) return 0;
     if (MODE == SRC_TEXT3) {
         if (gb + 4 < sv.nb) {
-            // 12 text bytes "HL HL HL HL " from a 4-byte aligned 16-byte load + funnel shifts
+            // a 4-byte aligned 16-byte load + funnel shifts by the frame's constant misalignment
             const uint8_t *a = sv.p + 3ull * gb;
             uint32_t s = (uint32_t)((uintptr_t)a & 3u);
             const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(a - s);
             uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
             uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
             uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
-            uint32_t fail = (not_hex4(t0) & 0x80008080u) | ((t0 ^ 0x00200000u) & 0x00FF0000u) |
-                            (not_hex4(t1) & 0x80800080u) | ((t1 ^ 0x00002000u) & 0x0000FF00u) |
-                            (not_hex4(t2) & 0x00808000u) | ((t2 ^ 0x20000020u) & 0xFF0000FFu);
-            if (fail) *not_strict = true;
-            uint32_t n0 = nib4(t0), n1 = nib4(t1), n2 = nib4(t2);
-            uint32_t b0 = ((n0 & 0xFu) << 4) | ((n0 >> 8) & 0xFu);
-            uint32_t b1 = (((n0 >> 24) & 0xFu) << 4) | (n1 & 0xFu);
-            uint32_t b2 = (((n1 >> 16) & 0xFu) << 4) | ((n1 >> 24) & 0xFu);
-            uint32_t b3 = (((n2 >> 8) & 0xFu) << 4) | ((n2 >> 16) & 0xFu);
-            return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            return decode12<VALIDATE>(t0, t1, t2, not_strict);
         }
         uint32_t val = 0;
         for (uint32_t k = 0; k < 4; k++) {
@@ -127,12 +142,50 @@ __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t
     }
 }
 
-template <int MODE>
+// Fill the wave's LDS tile (FRAME_TILE_DW dwords from data index tile_start).  dec_out (optional)
+// receives the tile's own 768 decoded dwords, so a later pass can read bytes instead of text.
+template <int MODE, bool VALIDATE>
 __device__ __forceinline__ void fill_tile(uint32_t *tile, const src_view &sv, uint32_t tile_start,
-                                          bool *not_strict)
+                                          bool *not_strict, uint32_t *dec_out)
 {
-    for (uint32_t d = lane_id(); d < (uint32_t)FRAME_TILE_DW; d += 64)
-        tile[d] = load_data_dword<MODE>(sv, tile_start + 4u * d, not_strict);
+    const uint32_t lane = lane_id();
+    const bool whole = (uint64_t)tile_start + 4ull * FRAME_TILE_DW + 8 < sv.nb;      // no end-of-data case inside
+    if (MODE == SRC_TEXT3 && whole) {
+        const uint8_t *a0 = sv.p + 3ull * tile_start;
+        const uint32_t s = (uint32_t)((uintptr_t)a0 & 3u);
+        const uint8_t *base = a0 - s + 12u * lane;
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(base + 768u * it);
+            uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
+            uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
+            uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
+            uint32_t v = decode12<VALIDATE>(t0, t1, t2, not_strict);
+            tile[lane + 64 * it] = v;
+            if (dec_out) dec_out[lane + 64 * it] = v;
+        }
+        if (lane < 4) {
+            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(base + 768u * 12);
+            uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
+            uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
+            uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
+            tile[768 + lane] = decode12<false>(t0, t1, t2, not_strict);      // halo: validated by its own tile
+        }
+        return;
+    }
+    if (MODE != SRC_TEXT3 && whole && (((uintptr_t)(sv.p + tile_start)) & 15u) == 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sv.p + tile_start);
+        uint4 *dst = reinterpret_cast<uint4 *>(tile);
+#pragma unroll
+        for (int it = 0; it < 3; it++) dst[lane + 64 * it] = src[lane + 64 * it];
+        if (lane == 0) dst[192] = src[192];
+        return;
+    }
+    for (uint32_t d = lane; d < (uint32_t)FRAME_TILE_DW; d += 64) {
+        uint32_t v = load_data_dword<MODE, VALIDATE>(sv, tile_start + 4u * d, not_strict);
+        tile[d] = v;
+        if (dec_out && d < (uint32_t)(FRAME_TILE / 4)) dec_out[d] = v;
+    }
 }
 
 // ---- per-run position masks -----------------------------------------------------------------------
@@ -163,25 +216,28 @@ __device__ __forceinline__ run_masks make_masks(const uint32_t *tile, int64_t re
         uint4 q = t4[i];
         w[4 * i + 0] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
     }
-    uint64_t b7 = 0, b6 = 0, zcc = 0, z33 = 0;
+    uint64_t b7 = 0, b6 = 0, fl = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         uint32_t x = w[i];
         b7 |= (uint64_t)movemask4((x >> 7) & 0x01010101u) << (4 * i);
         b6 |= (uint64_t)movemask4((x >> 6) & 0x01010101u) << (4 * i);
-        zcc |= (uint64_t)movemask4(zero_bytes4(x ^ 0xCCCCCCCCu) >> 7) << (4 * i);
-        z33 |= (uint64_t)movemask4(zero_bytes4(x ^ 0x33333333u) >> 7) << (4 * i);
+        // flag bytes: 0xCC ^ 0xCC = 0x00 and 0x33 ^ 0xCC = 0xFF; spread each byte's top bit over the
+        // byte and xor it away: both become 0x00, nothing else does
+        uint32_t y = x ^ 0xCCCCCCCCu;
+        uint32_t spread = ((y >> 7) & 0x01010101u) * 0xFFu;
+        fl |= (uint64_t)movemask4(zero_bytes4(y ^ spread) >> 7) << (4 * i);
     }
     const uint64_t own = (1ull << FRAME_RUN) - 1;
     uint64_t m0 = ~b7 & ~b6, m1 = ~b7 & b6, m2 = b7 & ~b6, m3 = b7 & b6;
     uint64_t c2 = m1 & (m1 >> 1);
     uint64_t c5 = c2 & (c2 >> 2) & (m1 >> 4);          // five CLK tags in a row
     uint64_t r3 = m2 & (m2 >> 1) & (m2 >> 2);          // three RSS tags in a row
-    uint64_t cand = (zcc | z33) & own;
+    uint64_t cand = fl & own;
     run_masks m;
     // bytes past the end are zero (tag 00), so a start whose record would run past the end fails the tags
     m.ok = cand & (m0 >> 1) & (m3 >> 2) & (c5 >> 3) & (r3 >> 8);
-    m.cc = zcc;
+    m.cc = fl & b7;                                     // 0xCC has its top bit set, 0x33 has not
     m.tail = 0;
     m.endbit = 0;
     if (rem < FRAME_RUN + 10 && rem > 0) {
@@ -242,7 +298,7 @@ __device__ __forceinline__ uint32_t resolve_entries(const run_masks &m, uint32_t
 // ---- pass 1: per tile, per entry offset: exit offset, records, discards -------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t nt_max, uint32_t *summ,
-                                                          uint32_t *stats)
+                                                          uint32_t *stats, uint8_t *dec, uint64_t dec_stride)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
@@ -257,7 +313,10 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
     }
     uint32_t *tile = lds[wv];
     const uint32_t tile_start = t * FRAME_TILE;
-    if (active) fill_tile<MODE>(tile, sv, tile_start, &not_strict);
+    if (active) {
+        uint32_t *dec_out = dec ? reinterpret_cast<uint32_t *>(dec + (size_t)f * dec_stride + tile_start) : nullptr;
+        fill_tile<MODE, true>(tile, sv, tile_start, &not_strict, dec_out);
+    }
     if (not_strict) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
     __syncthreads();
     if (!active) return;
@@ -389,7 +448,7 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
     bool not_strict = false;
     uint32_t *tile = lds[wv];
     const uint32_t tile_start = t * FRAME_TILE;
-    if (active) fill_tile<MODE>(tile, sv, tile_start, &not_strict);
+    if (active) fill_tile<MODE, false>(tile, sv, tile_start, &not_strict, nullptr);
     __syncthreads();
     if (!active) return;
 
@@ -431,28 +490,45 @@ uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
     return nt ? nt : 1;
 }
 
-void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[3])
+void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[4])
 {
     off[0] = p.add((size_t)F * nt_max * FRAME_SUMM_WORDS * sizeof(uint32_t));
     off[1] = p.add((size_t)F * nt_max);
     off[2] = p.add((size_t)F * nt_max * sizeof(uint32_t));
+    off[3] = p.add((size_t)F * dec_stride_for(nt_max));
 }
 
-int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t max_src_len,
+void frame_ws::bind(uint8_t *b, const size_t off[4], uint32_t nt_max)
+{
+    summ = (uint32_t *)(b + off[0]);
+    tile_entry = b + off[1];
+    tile_off = (uint32_t *)(b + off[2]);
+    dec = b + off[3];
+    dec_stride = dec_stride_for(nt_max);
+}
+
+int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, uint32_t max_src_len,
                  const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats)
 {
     (void)max_src_len;
     if (F == 0) return SLAM_OK;
     dim3 grid((nt_max + 3) / 4, F), block(256);
+    frame_src src = src_in;
+    src.dec = ws.dec;
+    src.dec_stride = ws.dec_stride;
+    src.stats = stats;
     if (mode == SRC_TEXT3) {
-        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats);
+        // pass 1 reads the text once, validates it and leaves the decoded bytes; pass 2 reads bytes
+        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats,
+                    ws.dec, ws.dec_stride);
     } else {
-        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_RAW>), grid, block, src, nt_max, ws.summ, stats);
+        SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_RAW>), grid, block, src, nt_max, ws.summ, stats,
+                    (uint8_t *)nullptr, (uint64_t)0);
     }
     SLAM_LAUNCH(ctx, "frame_scan", k_frame_scan, dim3(F), dim3(1024), ws.summ, nt_max, ws.tile_entry,
                 ws.tile_off, stats);
     if (mode == SRC_TEXT3) {
-        SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_TEXT3>), grid, block, src, nt_max, ws.tile_entry,
+        SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_DEC>), grid, block, src, nt_max, ws.tile_entry,
                     ws.tile_off, out);
     } else {
         SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_RAW>), grid, block, src, nt_max, ws.tile_entry,

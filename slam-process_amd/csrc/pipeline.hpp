@@ -8,19 +8,26 @@ constexpr int FRAME_TILE = 64 * FRAME_RUN;       // 3072 data bytes per wave til
 constexpr int FRAME_TILE_DW = FRAME_TILE / 4 + 4;  // tile + 16 halo bytes, in dwords
 constexpr int FRAME_SUMM_WORDS = 11;             // one packed word per entry offset 0..10
 
-enum { SRC_TEXT3 = 0, SRC_RAW = 1 };
+enum { SRC_TEXT3 = 0, SRC_RAW = 1, SRC_DEC = 2 };
 
 struct frame_src {
     const uint8_t *base;        // device: text (SRC_TEXT3) or data bytes (SRC_RAW) of all frames
     const uint64_t *off;        // device [F]
     const uint32_t *len;        // device [F]
+    const uint8_t *dec;         // device: bytes decoded by pass 1 (frame f at f*dec_stride), SRC_DEC only
+    uint64_t dec_stride;
+    const uint32_t *stats;      // device: SLAM_STAT_NBYTES gives each frame's decoded length (SRC_DEC)
 };
 
 struct frame_ws {               // device scratch of the framing stage
     uint32_t *summ;             // [F * nt_max * 11]
     uint8_t *tile_entry;        // [F * nt_max]
     uint32_t *tile_off;         // [F * nt_max]
-    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[3]);
+    uint8_t *dec;               // [F * dec_stride] decoded data bytes of text frames
+    uint64_t dec_stride;
+    static uint64_t dec_stride_for(uint32_t nt_max) { return (uint64_t)nt_max * FRAME_TILE + 256; }
+    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[4]);
+    void bind(uint8_t *base, const size_t off[4], uint32_t nt_max);
 };
 
 struct rows_out {               // decoded records, frame f at f*row_cap
@@ -56,8 +63,7 @@ struct correct_ws {
     int32_t *bl_clk, *bl_bs;                     // [F * bl_cap] baselines in row order
     uint32_t *bl_gid;                            // [F * bl_cap]
     uint32_t *srt_rb;                            // [F * bl_cap] per group: distinct clk_b mod cycle, ascending
-    int32_t *srt_clk, *srt_bs;                   // winner payload in the same order
-    uint32_t *srt_idx;                           // baseline index within its group (tie-break)
+    uint4 *srt_pay;                              // same order: (baseline index in group, clk_b div cycle, bs_b, 0)
     int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
@@ -67,9 +73,12 @@ struct correct_ws {
 };
 
 struct correct_params {
-    int32_t cycle, tol, mod_base;
-    int one_group;              // 1: the whole table is one group (UE wraps ignored)
-    int explicit_baselines;     // 1: baselines preloaded into bl_clk/bl_bs, count in stats BASELINES (implies one_group)
+    int32_t cycle = 0, tol = 0, mod_base = 0;
+    uint32_t div_m = 0, div_s1 = 0, div_s2 = 0;   // division by cycle as a multiply-high (set_cycle)
+    uint32_t bias = 0;                            // multiple of cycle >= 2^30 added to clocks before dividing
+    void set_cycle(int32_t c);
+    int one_group = 0;          // 1: the whole table is one group (UE wraps ignored)
+    int explicit_baselines = 0; // 1: baselines preloaded into bl_clk/bl_bs, count in stats BASELINES (implies one_group)
 };
 
 template <typename T8, typename T32>

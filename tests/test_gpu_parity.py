@@ -149,6 +149,8 @@ def test_correct_fuzz_against_oracle(ops):
         cyc = int(rng.choice([61000, 61001, 7, 2, 1000]))
         tol = int(rng.choice([500, 0, 3, cyc // 2, cyc]))
         clk = np.cumsum(rng.integers(0, 3 * cyc, n)) % (2 ** 30 - 1)
+        if trial % 4 == 1:
+            clk = clk - 2 ** 29                      # negative clocks: floor division / Python modulo semantics
         mod = int(rng.choice([64, 10, 255, 1]))
         kept_o, ng, nb = O.filter_corrected(flag, ue, bs, rss, clk, cyc, tol, mod)
         c = ops.correct(flag, ue, bs, rss, clk, cyc, tol, mod)
