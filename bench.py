@@ -35,9 +35,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--frames-per-step", type=int, default=50)
+    p.add_argument("--frames-per-step", type=int, default=100)
     p.add_argument("--beams", type=int, default=256, help="rows (UE sweeps) per frame")
     p.add_argument("--samples", type=int, default=4096, help="records per row")
     p.add_argument("--tile", type=int, default=1024)
@@ -170,12 +170,12 @@ def main():
     if kern:
         # algorithmic bytes each kernel must move per frame (its own inputs + outputs, no re-reads)
         alg = {
-            "frame_summarize": 3.0 * nbytes,
-            "frame_emit": 3.0 * nbytes + 11.0 * valid,
-            "rows_summarize": 6.0 * valid,
+            "frame_summarize": 3.0 * nbytes + nbytes,        # text in, decoded bytes out
+            "frame_emit": nbytes + 11.0 * valid,             # decoded bytes in, records out
+            "rows_summarize": 6.0 * valid,                   # ue, flag, rss
             "rows_groups": 6.0 * valid,
-            "rows_correct": 11.0 * valid,
-            "rows_emit_kept": 10.0 * valid + 10.0 * kept,
+            "rows_correct": 10.0 * valid + valid,            # flag, ue, rss, clk in; corrected-BS byte out
+            "rows_emit_kept": 10.0 * valid + 10.0 * kept,    # byte, ue, rss, clk in; kept rows out
             "pivot": 6.0 * kept,
             "raster": float(tile_bytes),
         }

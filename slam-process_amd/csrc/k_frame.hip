@@ -23,6 +23,7 @@ namespace {
 
 struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) u32x3_a1 { uint32_t v[3]; };
 
 struct src_view {
     const uint8_t *p;     // first token character (SRC_TEXT3) or first data byte (SRC_RAW / SRC_DEC)
@@ -62,7 +63,8 @@ __device__ __forceinline__ src_view resolve_src(const frame_src &s, uint32_t f)
 
 __device__ __forceinline__ uint32_t nib4(uint32_t w)
 {
-    return (w & 0x0F0F0F0Fu) + 9u * ((w >> 6) & 0x01010101u);
+    const uint32_t a = (w >> 6) & 0x01010101u;          // 1 for letters
+    return (w & 0x0F0F0F0Fu) + a + (a << 3);
 }
 
 // 0x80 in every byte of w that is not an ASCII hex digit
@@ -87,7 +89,7 @@ __device__ __forceinline__ int hexval(uint32_t c)
 // v_perm gathers the four high-nibble characters, the four low-nibble characters and the four
 // separators into one dword each; nibble values and the format check are then 4-wide SWAR.
 template <bool VALIDATE>
-__device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t t2, bool *not_strict)
+__device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t *bad)
 {
     const uint32_t ha = __builtin_amdgcn_perm(t1, t0, 0x0C060300u);
     const uint32_t h = __builtin_amdgcn_perm(t2, ha, 0x05020100u);
@@ -96,14 +98,14 @@ __device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t 
     if (VALIDATE) {
         const uint32_t sa = __builtin_amdgcn_perm(t1, t0, 0x0C0C0502u);
         const uint32_t sp = __builtin_amdgcn_perm(t2, sa, 0x07040100u);
-        if (not_hex4(h) | not_hex4(l) | (sp ^ 0x20202020u)) *not_strict = true;
+        *bad |= not_hex4(h) | not_hex4(l) | (sp ^ 0x20202020u);      // non-zero: not the strict capture format
     }
     return (nib4(h) << 4) | nib4(l);
 }
 
 // One dword (4 data bytes starting at data index gb) of a frame; zero beyond the end.
 template <int MODE, bool VALIDATE>
-__device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t gb, bool *not_strict)
+__device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t gb, uint32_t *bad)
 {
     if (gb >= sv.nb) return 0;
     if (MODE == SRC_TEXT3) {
@@ -115,7 +117,7 @@ __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t
             uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
             uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
             uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
-            return decode12<VALIDATE>(t0, t1, t2, not_strict);
+            return decode12<VALIDATE>(t0, t1, t2, bad);
         }
         uint32_t val = 0;
         for (uint32_t k = 0; k < 4; k++) {
@@ -124,8 +126,8 @@ __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t
             uint32_t o = 3u * b;
             int h = hexval(sv.p[o]);
             int l = (o + 1 < sv.n_src) ? hexval(sv.p[o + 1]) : -1;
-            if (h < 0 || l < 0) { *not_strict = true; h = 0; l = 0; }
-            if (o + 2 < sv.n_src && sv.p[o + 2] != 0x20) *not_strict = true;
+            if (h < 0 || l < 0) { *bad |= 1u; h = 0; l = 0; }
+            if (o + 2 < sv.n_src && sv.p[o + 2] != 0x20) *bad |= 1u;
             val |= (uint32_t)((h << 4) | l) << (8 * k);
         }
         return val;
@@ -146,30 +148,25 @@ __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t
 // receives the tile's own 768 decoded dwords, so a later pass can read bytes instead of text.
 template <int MODE, bool VALIDATE>
 __device__ __forceinline__ void fill_tile(uint32_t *tile, const src_view &sv, uint32_t tile_start,
-                                          bool *not_strict, uint32_t *dec_out)
+                                          uint32_t *bad, uint32_t *dec_out)
 {
     const uint32_t lane = lane_id();
     const bool whole = (uint64_t)tile_start + 4ull * FRAME_TILE_DW + 8 < sv.nb;      // no end-of-data case inside
     if (MODE == SRC_TEXT3 && whole) {
-        const uint8_t *a0 = sv.p + 3ull * tile_start;
-        const uint32_t s = (uint32_t)((uintptr_t)a0 & 3u);
-        const uint8_t *base = a0 - s + 12u * lane;
+        // 12 text bytes per lane per step, contiguous across the wave (768 bytes per load instruction);
+        // the loads are byte-aligned only (the "« " prefix shifts every token by 3), which global
+        // loads on this target accept
+        const uint8_t *base = sv.p + 3ull * tile_start + 12u * lane;
 #pragma unroll
         for (int it = 0; it < 12; it++) {
-            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(base + 768u * it);
-            uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
-            uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
-            uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
-            uint32_t v = decode12<VALIDATE>(t0, t1, t2, not_strict);
+            const u32x3_a1 q = *reinterpret_cast<const u32x3_a1 *>(base + 768u * it);
+            uint32_t v = decode12<VALIDATE>(q.v[0], q.v[1], q.v[2], bad);
             tile[lane + 64 * it] = v;
             if (dec_out) dec_out[lane + 64 * it] = v;
         }
         if (lane < 4) {
-            const u32x4_a4 q = *reinterpret_cast<const u32x4_a4 *>(base + 768u * 12);
-            uint32_t t0 = __builtin_amdgcn_alignbyte(q.v[1], q.v[0], s);
-            uint32_t t1 = __builtin_amdgcn_alignbyte(q.v[2], q.v[1], s);
-            uint32_t t2 = __builtin_amdgcn_alignbyte(q.v[3], q.v[2], s);
-            tile[768 + lane] = decode12<false>(t0, t1, t2, not_strict);      // halo: validated by its own tile
+            const u32x3_a1 q = *reinterpret_cast<const u32x3_a1 *>(base + 768u * 12);
+            tile[768 + lane] = decode12<false>(q.v[0], q.v[1], q.v[2], bad);     // halo: validated by its own tile
         }
         return;
     }
@@ -182,7 +179,7 @@ __device__ __forceinline__ void fill_tile(uint32_t *tile, const src_view &sv, ui
         return;
     }
     for (uint32_t d = lane; d < (uint32_t)FRAME_TILE_DW; d += 64) {
-        uint32_t v = load_data_dword<MODE, VALIDATE>(sv, tile_start + 4u * d, not_strict);
+        uint32_t v = load_data_dword<MODE, VALIDATE>(sv, tile_start + 4u * d, bad);
         tile[d] = v;
         if (dec_out && d < (uint32_t)(FRAME_TILE / 4)) dec_out[d] = v;
     }
@@ -198,7 +195,12 @@ struct run_masks {
     uint64_t endbit;  // where a visited tail position sends the orbit (first position past the data)
 };
 
-__device__ __forceinline__ uint32_t movemask4(uint32_t x01) { return (x01 * 0x01020408u) >> 24; }
+// bits 0, 8, 16, 24 of x01 -> bits 0..3
+__device__ __forceinline__ uint32_t movemask4(uint32_t x01)
+{
+    uint32_t t = x01 | (x01 >> 7);
+    return (t | (t >> 14)) & 0xFu;
+}
 
 __device__ __forceinline__ uint32_t zero_bytes4(uint32_t v)   // 0x80 in every zero byte, exact
 {
@@ -225,7 +227,8 @@ __device__ __forceinline__ run_masks make_masks(const uint32_t *tile, int64_t re
         // flag bytes: 0xCC ^ 0xCC = 0x00 and 0x33 ^ 0xCC = 0xFF; spread each byte's top bit over the
         // byte and xor it away: both become 0x00, nothing else does
         uint32_t y = x ^ 0xCCCCCCCCu;
-        uint32_t spread = ((y >> 7) & 0x01010101u) * 0xFFu;
+        uint32_t top = (y >> 7) & 0x01010101u;
+        uint32_t spread = (top << 8) - top;
         fl |= (uint64_t)movemask4(zero_bytes4(y ^ spread) >> 7) << (4 * i);
     }
     const uint64_t own = (1ull << FRAME_RUN) - 1;
@@ -252,15 +255,21 @@ __device__ __forceinline__ run_masks make_masks(const uint32_t *tile, int64_t re
 }
 
 // All positions (bits 0..58) an orbit entering at the seed positions visits.
+// A run of 48 positions holds at most 5 records on one orbit (starts >= 11 apart), so five
+// walk-then-jump rounds plus a last walk reach everything.  Tail positions are neither walkable nor
+// record starts; if one was visited the orbit continues from the first position past the data.
 __device__ __forceinline__ uint64_t closure(uint64_t seed, const run_masks &m)
 {
     uint64_t v = seed;
-    for (int it = 0; it < 12; it++) {
-        uint64_t f = (((m.walk & v) + m.walk) ^ m.walk) | v;   // walk +1 through non-record positions
-        uint64_t n = f | ((f & m.ok) << 11);                   // jump over each visited record
-        if (f & m.tail) n |= m.endbit;
-        if (n == v) break;
-        v = n;
+#pragma unroll
+    for (int it = 0; it < 5; it++) {
+        v |= ((m.walk & v) + m.walk) ^ m.walk;                 // walk +1 through non-record positions
+        v |= (v & m.ok) << 11;                                 // jump over each visited record
+    }
+    v |= ((m.walk & v) + m.walk) ^ m.walk;
+    if (v & m.tail) {
+        v |= m.endbit;
+        v |= ((m.walk & v) + m.walk) ^ m.walk;
     }
     return v;
 }
@@ -306,18 +315,18 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     const bool active = t < nt;
-    bool not_strict = false;
+    uint32_t bad = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES] = sv.nb;
-        if (sv.bad) not_strict = true;
+        if (sv.bad) bad = 1;
     }
     uint32_t *tile = lds[wv];
     const uint32_t tile_start = t * FRAME_TILE;
     if (active) {
         uint32_t *dec_out = dec ? reinterpret_cast<uint32_t *>(dec + (size_t)f * dec_stride + tile_start) : nullptr;
-        fill_tile<MODE, true>(tile, sv, tile_start, &not_strict, dec_out);
+        fill_tile<MODE, true>(tile, sv, tile_start, &bad, dec_out);
     }
-    if (not_strict) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
+    if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
     __syncthreads();
     if (!active) return;
 
@@ -445,10 +454,10 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     const bool active = t < nt;
-    bool not_strict = false;
+    uint32_t bad = 0;
     uint32_t *tile = lds[wv];
     const uint32_t tile_start = t * FRAME_TILE;
-    if (active) fill_tile<MODE, false>(tile, sv, tile_start, &not_strict, nullptr);
+    if (active) fill_tile<MODE, false>(tile, sv, tile_start, &bad, nullptr);
     __syncthreads();
     if (!active) return;
 

@@ -102,26 +102,28 @@ __device__ void blur_block(const double *in, int h, int w, const double *kern, i
     }
 }
 
-// finite min / max of m[0..n) across the block; sh needs 2*256 doubles.  Returns false when none is finite.
+// finite min / max of m[0..n) across the block (blockDim.x a power of two <= 1024); sh needs 2*blockDim.x
+// doubles.  Returns false when none is finite.
 __device__ bool block_minmax(const double *m, int n, double *sh, double *mn, double *mx)
 {
+    const int T = blockDim.x;
     double lo = INFINITY, hi = -INFINITY;
-    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    for (int c = threadIdx.x; c < n; c += T) {
         double v = m[c];
         if (finite_d(v)) { lo = fmin(lo, v); hi = fmax(hi, v); }
     }
     sh[threadIdx.x] = lo;
-    sh[256 + threadIdx.x] = hi;
+    sh[T + threadIdx.x] = hi;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = T / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             sh[threadIdx.x] = fmin(sh[threadIdx.x], sh[threadIdx.x + s]);
-            sh[256 + threadIdx.x] = fmax(sh[256 + threadIdx.x], sh[256 + threadIdx.x + s]);
+            sh[T + threadIdx.x] = fmax(sh[T + threadIdx.x], sh[T + threadIdx.x + s]);
         }
         __syncthreads();
     }
     *mn = sh[0];
-    *mx = sh[256];
+    *mx = sh[T];
     __syncthreads();
     return *mn <= *mx;
 }
@@ -194,12 +196,12 @@ __device__ __forceinline__ void put_f64_stat(uint32_t *stats, int lo_word, doubl
 }
 
 // One workgroup per frame: sum/cnt -> mean grid -> compact -> blur -> scale -> cells + pixel maps.
-__global__ __launch_bounds__(256) void k_frame_matrix(render_params rp, render_ws ws, const double *kern, int ks,
+__global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_ws ws, const double *kern, int ks,
                                                        double *matrix, double *blurred, uint32_t *stats)
 {
     __shared__ double cm[MAX_CELLS];
     __shared__ double bm[MAX_CELLS];
-    __shared__ double red[512];
+    __shared__ double red[2048];
     __shared__ double ang_r[MAX_AXIS], ang_c[MAX_AXIS], edge[MAX_AXIS + 1];
     __shared__ uint32_t rowp[MAX_AXIS], colp[MAX_AXIS];
     __shared__ int ridx[MAX_AXIS], cidx[MAX_AXIS];
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void k_frame_matrix(render_params rp, render_w
     uint32_t *st = stats + f * SLAM_STAT_WORDS;
     if (tid < MAX_AXIS) { rowp[tid] = 0; colp[tid] = 0; }
     __syncthreads();
-    for (int c = tid; c < na * na; c += 256) {
+    for (int c = tid; c < na * na; c += 1024) {
         const uint32_t k = cnt[c];
         const double mean = k ? (double)(long long)sum[c] / (double)k : __longlong_as_double(0x7FF8000000000000ll);
         if (matrix) matrix[(size_t)f * na * na + c] = mean;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void k_frame_matrix(render_params rp, render_w
         if (tid == 0) st[SLAM_STAT_ALLNAN] = 1;
         return;
     }
-    for (int c = tid; c < h * w; c += 256) {
+    for (int c = tid; c < h * w; c += 1024) {
         const int src = ridx[c / w] * na + cidx[c % w];
         const uint32_t k = cnt[src];
         cm[c] = k ? (double)(long long)sum[src] / (double)k : __longlong_as_double(0x7FF8000000000000ll);
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void k_frame_matrix(render_params rp, render_w
         fin = bm;
     }
     if (blurred)
-        for (int c = tid; c < h * w; c += 256) blurred[(size_t)f * na * na + c] = fin[c];
+        for (int c = tid; c < h * w; c += 1024) blurred[(size_t)f * na * na + c] = fin[c];
     double mn, mx;
     const bool any = block_minmax(fin, h * w, red, &mn, &mx);
     uint8_t *cells = ws.cells + (size_t)f * MAX_CELLS * 4;
@@ -405,7 +407,7 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
                        int ks, double *matrix, double *blurred, uint8_t *tile, uint32_t *stats)
 {
     if (F == 0) return SLAM_OK;
-    SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(256), rp, ws, kern, ks, matrix, blurred, stats);
+    SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(1024), rp, ws, kern, ks, matrix, blurred, stats);
     if (tile) {
         const uint32_t groups = (uint32_t)((rp.W + 3) / 4) * (uint32_t)rp.H;
         SLAM_LAUNCH(ctx, "raster", k_raster, dim3((groups + 255) / 256, F), dim3(256), ws.cells, ws.colmap,

@@ -78,6 +78,18 @@ __global__ __launch_bounds__(256) void k_copy16(uint4 *dst, const uint4 *src, si
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// read-only stream: xor of everything, one word written per workgroup (bandwidth probe)
+__global__ __launch_bounds__(256) void k_read16(uint32_t *dst, const uint4 *src, size_t n16)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    acc = wave_sum(acc);
+    if (lane_id() == 0) dst[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
+}
+
 }  // namespace
 
 extern "C" size_t slam_synth_text_len(uint32_t B, uint32_t N)
@@ -102,6 +114,10 @@ extern "C" int slam_copy_probe_dev(slam_ctx *ctx, void *dst_dev, const void *src
 {
     if (!ctx) return SLAM_E_INVALID;
     if (!dst_dev || !src_dev || (n & 15)) return slam_fail(ctx, SLAM_E_INVALID, "copy probe needs 16-byte multiples");
+    if (dst_dev == src_dev) {       // same pointer: read-only probe (writes 32 KiB of per-workgroup words at dst)
+        SLAM_LAUNCH(ctx, "read_probe", k_read16, dim3(2048), dim3(256), (uint32_t *)dst_dev, (const uint4 *)src_dev + 2048, n / 16 - 2048);
+        return SLAM_OK;
+    }
     SLAM_LAUNCH(ctx, "copy_probe", k_copy16, dim3(2048), dim3(256), (uint4 *)dst_dev, (const uint4 *)src_dev, n / 16);
     return SLAM_OK;
 }

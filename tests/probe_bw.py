@@ -1,0 +1,21 @@
+"""Device bandwidth probe (not a test): copy and read-only streams through slam_copy_probe_dev."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "slam-process_amd"))
+import torch
+from slamhip import _lib
+c = _lib.ctx(0)
+n = 4 << 30
+a = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 255)
+b = torch.empty(n, dtype=torch.uint8, device="cuda")
+c.set_stream(torch.cuda.current_stream().cuda_stream)
+for name, dst, src, traffic in (("copy", b, a, 2 * n), ("read", a, a, n)):
+    for _ in range(3):
+        c.check(c.lib.slam_copy_probe_dev(c.h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        c.check(c.lib.slam_copy_probe_dev(c.h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print(f"{name}: {traffic / dt / 1e12:.2f} TB/s ({dt * 1e3:.3f} ms per {n >> 20} MiB)")
