@@ -189,8 +189,15 @@ def main():
         dom = max((n for n in kern if n in alg), key=lambda n: kern[n][1])
         per = kern[dom][1] / kern[dom][0]
         ach = alg[dom] * F / (per * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 PMC passes (same shape)
+            pj = json.load(open(pmc))
+            if pj.get("shape") == [B, N] and dom in pj["kernels"]:
+                kk = pj["kernels"][dom]
+                traffic = int((kk["fetch_bytes_per_frame"] + kk["write_bytes_per_frame"]) * F)
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                     alg_bytes_per_launch=int(alg[dom] * F), avg_launch_ms=round(per, 5))
 
     out = {
