@@ -1,0 +1,91 @@
+"""Whole captures in, per-capture results out: the three reference scripts' chain without workbooks.
+
+`process_texts` packs any number of capture texts (different lengths) into one device buffer and runs
+slam_process_frames_dev once.  Texts that are not in the strict capture format ("XX XX ..." with an
+optional leading "« ") are unpacked by the exact general tokenizer (slam_hex_unpack) and re-run as byte
+frames.  `process_files_sharded` does the same for the files one rank owns and gathers the tiles.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .pipeline import FramePipeline, STAGE_ALL
+
+
+def _pack(chunks: Sequence[np.ndarray], device) -> tuple:
+    offs, lens, pos = [], [], 0
+    for c in chunks:
+        offs.append(pos)
+        lens.append(len(c))
+        pos += (len(c) + 255) // 256 * 256
+    buf = np.zeros(pos + 256, np.uint8)
+    for o, c in zip(offs, chunks):
+        buf[o:o + len(c)] = c
+    return torch.from_numpy(buf).to(device), offs, lens
+
+
+def _collect(pipe: FramePipeline, n: int) -> List[Dict]:
+    st = pipe.stats_host()
+    out = []
+    for f in range(n):
+        full, bl, aod, aoa, lo, hi = pipe.frame_matrix(f, st)
+        out.append(dict(stats=st[f].copy(), rows=pipe.frame_rows(f, st), kept=pipe.frame_kept(f, st),
+                        matrix=full, blurred=bl, aod=aod, aoa=aoa, vmin=lo, vmax=hi, tile=pipe.frame_tile(f)))
+    return out
+
+
+def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, **pipeline_kwargs) -> List[Dict]:
+    """Every text through decode -> correct -> pivot -> blur -> raster on the GPU; one dict per text."""
+    if not texts:
+        return []
+    dev = torch.device("cuda", device)
+    arrs = [np.frombuffer(bytes(t), np.uint8) for t in texts]
+    buf, offs, lens = _pack(arrs, dev)
+    pipe = FramePipeline(len(arrs), max(max(lens), 1), device=device, tile_w=tile, tile_h=tile, **pipeline_kwargs)
+    pipe.set_layout(offs, lens)
+    pipe.run(buf, stages=STAGE_ALL)
+    res = _collect(pipe, len(arrs))
+    loose = [i for i, r in enumerate(res) if r["stats"][_lib.STAT_NOT_STRICT]]
+    if loose:
+        data = [ops.hex_unpack(arrs[i], device=device) for i in loose]
+        bbuf, boffs, blens = _pack(data, dev)
+        bpipe = FramePipeline(len(data), max(max(blens), 1), device=device, tile_w=tile, tile_h=tile,
+                              src_is_bytes=True, **pipeline_kwargs)
+        bpipe.set_layout(boffs, blens)
+        bpipe.run(bbuf, stages=STAGE_ALL)
+        for i, r in zip(loose, _collect(bpipe, len(data))):
+            res[i] = r
+    return res
+
+
+def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 1024, **pipeline_kwargs):
+    """Under torch.distributed: each rank processes the files `balance_files` gives it; rank 0 receives every
+    file's tile (list indexed like `paths`), other ranks None.  Without an initialised process group: all files."""
+    import os
+    import torch.distributed as dist
+    from . import dist as D
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    sizes = [os.path.getsize(p) for p in paths]
+    bins = D.balance_files(sizes, world)
+    mine = bins[rank]
+    res = process_texts([open(paths[i], "rb").read() for i in mine], device=device, tile=tile, **pipeline_kwargs)
+    if world == 1:
+        return [r["tile"] for r in res], res
+    per = max(len(b) for b in bins)
+    dev = torch.device("cuda", device)
+    tiles = torch.zeros((per, tile, tile, 4), dtype=torch.uint8, device=dev)
+    for j, r in enumerate(res):
+        tiles[j] = torch.from_numpy(r["tile"]).to(dev)
+    got = D.gather_tiles(tiles, dst=0)
+    if rank != 0:
+        return None, res
+    out: List[Optional[np.ndarray]] = [None] * len(paths)
+    for r, b in enumerate(bins):
+        for j, i in enumerate(b):
+            out[i] = got[r][j].cpu().numpy()
+    return out, res

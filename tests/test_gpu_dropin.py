@@ -154,3 +154,61 @@ def test_full_size_frames_bit_exact():
         # size-independent property: the tile holds exactly the colours of the cells
         tile = pipe.frame_tile(f)
         assert set(map(tuple, tile.reshape(-1, 4)[::97])) <= set(map(tuple, r["cells"].reshape(-1, 4)))
+
+
+def test_ragged_batch_of_captures_with_loose_text():
+    """Captures of different lengths in one batch (the shape of 'all debugDoc logs batched'); one of them is
+    free-form text, which the batched call flags and the general tokenizer then handles."""
+    import json
+    from slamhip.batch import process_texts
+    from slamhip.pipeline import default_mapping, viridis_lut
+    mapping, lut = default_mapping(), viridis_lut()
+    zs = [np.load(os.path.join(GOLDEN, f"log{i}.npz")) for i in range(3)]
+    texts = [z["text"].tobytes() for z in zs]
+    loose = b"0x33 0x05\n0xC7 41 42 43 44 45 81 82 83   33 05 C7 41 42 43 44 45 81 82 83 cc 05 c7 41 42 43 44 45 81 82 83"
+    res = process_texts(texts + [loose, b""], tile=64)
+    for z, r in zip(zs, res):
+        assert int(r["stats"][1]) == 0
+        assert (int(r["stats"][2]), int(r["stats"][3])) == (int(z["valid"]), int(z["discarded"]))
+        got = np.stack([r["rows"][k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1)
+        assert np.array_equal(got, z["rows"])
+        kept = np.stack([r["kept"][k].astype(np.int64) for k in ("ue", "bs", "rss", "clk")], 1)
+        assert np.array_equal(kept, z["kept"])
+        mat, aod, aoa, so, co = O.pivot_mean(z["kept"][:, 0], z["kept"][:, 1], z["kept"][:, 2], mapping)
+        rr = O.render(r["blurred"], aod, aoa, lut, use_log=False, blur_sigma=0.0, W=64, H=64)
+        assert np.array_equal(r["tile"], rr["tile"])
+    by = O.read_bytes(loose)
+    rows_o, v, d = O.parse_groups(by)
+    assert v == 3 and int(res[3]["stats"][2]) == 3 and np.array_equal(res[3]["rows"]["flag"], rows_o["flag"])
+    assert int(res[4]["stats"][2]) == 0 and int(res[4]["stats"][9]) == 1      # empty capture: nothing, blank tile
+
+
+@pytest.mark.parametrize("shape", [(256, 16384), (1024, 8192)])
+def test_long_sweep_and_wide_frames_bit_exact(shape):
+    """BASELINE.json's other synthetic shapes (256 x 16384 long sweeps, 1024 x 8192) against the oracle."""
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+    B, N = shape
+    tl = synth.text_len(B, N)
+    text = synth_frames(1, B, N, first_frame=7)
+    mapping, lut = default_mapping(), viridis_lut()
+    pipe = FramePipeline(1, tl, tile_w=256, tile_h=256, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(1, tl, tl)
+    pipe.run(text)
+    st = pipe.stats_host()
+    by = O.read_bytes(text[:tl].cpu().numpy().tobytes())
+    rows_o, v, d = O.parse_groups(by)
+    assert (int(st[0, 0]), int(st[0, 1]), int(st[0, 2]), int(st[0, 3])) == (len(by), 0, v, d)
+    rows = pipe.frame_rows(0, st)
+    for k in rows_o:
+        assert np.array_equal(rows[k], rows_o[k]), k
+    kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+    assert (int(st[0, 4]), int(st[0, 5]), int(st[0, 6])) == (ng, nb, len(kept_o["ue"])) and ng == B
+    kept = pipe.frame_kept(0, st)
+    for k in kept_o:
+        assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+    mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
+    full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(0, st)
+    assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+    r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=256)
+    assert np.array_equal(pipe.frame_tile(0), r["tile"])
