@@ -588,7 +588,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[4], cw[16], rw[5];
+    size_t fw[5], cw[16], rw[5];
     uint32_t nt_max, bl_cap;
     size_t total;
 };

@@ -23,7 +23,6 @@ namespace {
 
 struct __attribute__((packed, aligned(4))) u32x4_a4 { uint32_t v[4]; };
 struct __attribute__((packed, aligned(4))) u32x2_a4 { uint32_t v[2]; };
-struct __attribute__((packed, aligned(1))) u32x3_a1 { uint32_t v[3]; };
 
 struct src_view {
     const uint8_t *p;     // first token character (SRC_TEXT3) or first data byte (SRC_RAW / SRC_DEC)
@@ -32,33 +31,59 @@ struct src_view {
     bool bad;             // text length cannot be a whole number of "XX " tokens
 };
 
+// Per-frame source description, prepared once per batch so the tile kernels start with one 16-byte load
+// instead of a chain of dependent reads (offset table -> text prefix).
 template <int MODE>
-__device__ __forceinline__ src_view resolve_src(const frame_src &s, uint32_t f)
+__global__ __launch_bounds__(256) void k_frame_prepare(frame_src s, uint32_t F, frame_desc *fd, uint32_t *stats)
 {
-    src_view v;
-    v.bad = false;
-    if (MODE == SRC_DEC) {                 // bytes decoded by pass 1 of this launch sequence
-        v.p = s.dec + (size_t)f * s.dec_stride;
-        v.nb = s.stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES];
-        v.n_src = v.nb;
-        return v;
-    }
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
     const uint8_t *p = s.base + s.off[f];
-    uint32_t n = s.len[f];
+    const uint32_t n = s.len[f];
+    frame_desc d;
+    bool bad = false;
     if (MODE == SRC_TEXT3) {
         uint32_t pre = 0;
         if (n >= 3 && p[0] == 0xC2 && p[1] == 0xAB && p[2] == 0x20) pre = 3;   // leading "« "
-        uint32_t L = n - pre;
-        v.p = p + pre;
-        v.n_src = L;
-        v.nb = (L + 1) / 3;
-        v.bad = (L % 3) == 1;
+        const uint32_t L = n - pre;
+        d.off = s.off[f] + pre;
+        d.n_src = L;
+        d.nb = (L + 1) / 3;
+        bad = (L % 3) == 1;              // a dangling character: not a whole number of "XX " tokens
     } else {
-        v.p = p;
-        v.n_src = n;
-        v.nb = n;
+        d.off = s.off[f];
+        d.n_src = n;
+        d.nb = n;
+    }
+    fd[f] = d;
+    stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES] = d.nb;
+    if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
+}
+
+template <int MODE>
+__device__ __forceinline__ src_view resolve_src(const frame_src &s, uint32_t f)
+{
+    const frame_desc d = s.fdesc[f];
+    src_view v;
+    v.bad = false;
+    v.nb = d.nb;
+    if (MODE == SRC_DEC) {                 // bytes decoded by pass 1 of this launch sequence
+        v.p = s.dec + (size_t)f * s.dec_stride;
+        v.n_src = d.nb;
+    } else {
+        v.p = s.base + d.off;
+        v.n_src = d.n_src;
     }
     return v;
+}
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware runs a wave's LDS
+// operations in order, so only the compiler has to be told not to move them across this point.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ uint32_t nib4(uint32_t w)
@@ -153,20 +178,34 @@ __device__ __forceinline__ void fill_tile(uint32_t *tile, const src_view &sv, ui
     const uint32_t lane = lane_id();
     const bool whole = (uint64_t)tile_start + 4ull * FRAME_TILE_DW + 8 < sv.nb;      // no end-of-data case inside
     if (MODE == SRC_TEXT3 && whole) {
-        // 12 text bytes per lane per step, contiguous across the wave (768 bytes per load instruction);
-        // the loads are byte-aligned only (the "« " prefix shifts every token by 3), which global
-        // loads on this target accept
-        const uint8_t *base = sv.p + 3ull * tile_start + 12u * lane;
+        // 12 text bytes per lane per step, contiguous across the wave.  The "« " prefix shifts every token
+        // by 3 bytes, so each lane loads the 16 aligned bytes that cover its 12 and funnel-shifts them by the
+        // frame's constant misalignment.  All loads are issued before anything is stored: the stores may
+        // alias the text as far as the compiler knows, and would otherwise serialise the loads.
+        const uint8_t *a0 = sv.p + 3ull * tile_start;
+        const uint32_t s = (uint32_t)((uintptr_t)a0 & 3u);
+        const uint8_t *base = a0 - s + 12u * lane;
+        u32x4_a4 q[12];
+#pragma unroll
+        for (int it = 0; it < 12; it++) q[it] = *reinterpret_cast<const u32x4_a4 *>(base + 768u * it);
+        u32x4_a4 qh;
+        qh.v[0] = qh.v[1] = qh.v[2] = qh.v[3] = 0;
+        if (lane < 4) qh = *reinterpret_cast<const u32x4_a4 *>(base + 768u * 12);
 #pragma unroll
         for (int it = 0; it < 12; it++) {
-            const u32x3_a1 q = *reinterpret_cast<const u32x3_a1 *>(base + 768u * it);
-            uint32_t v = decode12<VALIDATE>(q.v[0], q.v[1], q.v[2], bad);
+            uint32_t t0 = __builtin_amdgcn_alignbyte(q[it].v[1], q[it].v[0], s);
+            uint32_t t1 = __builtin_amdgcn_alignbyte(q[it].v[2], q[it].v[1], s);
+            uint32_t t2 = __builtin_amdgcn_alignbyte(q[it].v[3], q[it].v[2], s);
+            uint32_t v = decode12<VALIDATE>(t0, t1, t2, bad);
             tile[lane + 64 * it] = v;
             if (dec_out) dec_out[lane + 64 * it] = v;
         }
         if (lane < 4) {
-            const u32x3_a1 q = *reinterpret_cast<const u32x3_a1 *>(base + 768u * 12);
-            tile[768 + lane] = decode12<false>(q.v[0], q.v[1], q.v[2], bad);     // halo: validated by its own tile
+            uint32_t t0 = __builtin_amdgcn_alignbyte(qh.v[1], qh.v[0], s);
+            uint32_t t1 = __builtin_amdgcn_alignbyte(qh.v[2], qh.v[1], s);
+            uint32_t t2 = __builtin_amdgcn_alignbyte(qh.v[3], qh.v[2], s);
+            uint32_t dummy = 0;
+            tile[768 + lane] = decode12<false>(t0, t1, t2, &dummy);           // halo: validated by its own tile
         }
         return;
     }
@@ -305,30 +344,26 @@ __device__ __forceinline__ uint32_t resolve_entries(const run_masks &m, uint32_t
 }
 
 // ---- pass 1: per tile, per entry offset: exit offset, records, discards -------------------------
+// Each wave owns its LDS tile and walks FRAME_TPW tiles; waves never wait for each other.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t nt_max, uint32_t *summ,
                                                           uint32_t *stats, uint8_t *dec, uint64_t dec_stride)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t t = blockIdx.x * 4 + wv;
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
-    const bool active = t < nt;
-    uint32_t bad = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES] = sv.nb;
-        if (sv.bad) bad = 1;
-    }
     uint32_t *tile = lds[wv];
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < FRAME_TPW; j++) {
+    const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+    if (t >= nt) break;
     const uint32_t tile_start = t * FRAME_TILE;
-    if (active) {
+    {
         uint32_t *dec_out = dec ? reinterpret_cast<uint32_t *>(dec + (size_t)f * dec_stride + tile_start) : nullptr;
         fill_tile<MODE, true>(tile, sv, tile_start, &bad, dec_out);
     }
-    if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
-    __syncthreads();
-    if (!active) return;
+    wave_lds_sync();
 
     const run_masks m = make_masks(tile, (int64_t)sv.nb - (int64_t)tile_start - (int64_t)lane * FRAME_RUN);
     const uint64_t vall = closure(0x7FFull, m);                  // all 11 entry offsets at once
@@ -341,10 +376,10 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
     // lanes 0..10 chain entry offset e = lane through runs 0..s (run s included)
     uint32_t e = lane < 11 ? lane : 0, accv = 0, accd = 0;
     const uint32_t last = s < 64 ? s : 63;
-    for (uint32_t j = 0; j <= last; j++) {
+    for (uint32_t q = 0; q <= last; q++) {
         run_masks mj;
-        mj.ok = shfl64(m.ok, j); mj.rej = shfl64(m.rej, j); mj.tail = shfl64(m.tail, j);
-        mj.walk = shfl64(m.walk, j); mj.endbit = shfl64(m.endbit, j); mj.cc = 0;
+        mj.ok = shfl64(m.ok, q); mj.rej = shfl64(m.rej, q); mj.tail = shfl64(m.tail, q);
+        mj.walk = shfl64(m.walk, q); mj.endbit = shfl64(m.endbit, q); mj.cc = 0;
         uint64_t v = closure(1ull << e, mj);
         accv += count_valid(v, mj);
         accd += count_disc(v, mj);
@@ -382,6 +417,9 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
         summ[((size_t)f * nt_max + t) * FRAME_SUMM_WORDS + lane] =
             (exit_e << 28) | ((accv + restv) << 16) | (accd + restd);
     }
+    wave_lds_sync();
+    }
+    if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
 }
 
 // ---- per-frame scan over tiles --------------------------------------------------------------------
@@ -450,16 +488,16 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t t = blockIdx.x * 4 + wv;
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
-    const bool active = t < nt;
     uint32_t bad = 0;
     uint32_t *tile = lds[wv];
+    for (uint32_t j = 0; j < FRAME_TPW; j++) {
+    const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+    if (t >= nt) break;
     const uint32_t tile_start = t * FRAME_TILE;
-    if (active) fill_tile<MODE, false>(tile, sv, tile_start, &bad, nullptr);
-    __syncthreads();
-    if (!active) return;
+    fill_tile<MODE, false>(tile, sv, tile_start, &bad, nullptr);
+    wave_lds_sync();
 
     const run_masks m = make_masks(tile, (int64_t)sv.nb - (int64_t)tile_start - (int64_t)lane * FRAME_RUN);
     const uint64_t exits = closure(0x7FFull, m) >> FRAME_RUN;
@@ -488,6 +526,8 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
         out.rss[o] = (d2 & 63u) | (((d2 >> 8) & 63u) << 6) | (((d2 >> 16) & 63u) << 12);
         o++;
     }
+    wave_lds_sync();
+    }
 }
 
 }  // namespace
@@ -499,16 +539,18 @@ uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
     return nt ? nt : 1;
 }
 
-void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[4])
+void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[5])
 {
+    off[4] = p.add((size_t)F * sizeof(frame_desc));
     off[0] = p.add((size_t)F * nt_max * FRAME_SUMM_WORDS * sizeof(uint32_t));
     off[1] = p.add((size_t)F * nt_max);
     off[2] = p.add((size_t)F * nt_max * sizeof(uint32_t));
     off[3] = p.add((size_t)F * dec_stride_for(nt_max));
 }
 
-void frame_ws::bind(uint8_t *b, const size_t off[4], uint32_t nt_max)
+void frame_ws::bind(uint8_t *b, const size_t off[5], uint32_t nt_max)
 {
+    fdesc = (frame_desc *)(b + off[4]);
     summ = (uint32_t *)(b + off[0]);
     tile_entry = b + off[1];
     tile_off = (uint32_t *)(b + off[2]);
@@ -521,11 +563,16 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, u
 {
     (void)max_src_len;
     if (F == 0) return SLAM_OK;
-    dim3 grid((nt_max + 3) / 4, F), block(256);
+    dim3 grid((nt_max + 4 * FRAME_TPW - 1) / (4 * FRAME_TPW), F), block(256);
     frame_src src = src_in;
     src.dec = ws.dec;
     src.dec_stride = ws.dec_stride;
-    src.stats = stats;
+    src.fdesc = ws.fdesc;
+    if (mode == SRC_TEXT3) {
+        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_TEXT3>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc, stats);
+    } else {
+        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_RAW>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc, stats);
+    }
     if (mode == SRC_TEXT3) {
         // pass 1 reads the text once, validates it and leaves the decoded bytes; pass 2 reads bytes
         SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats,

@@ -90,7 +90,48 @@ __global__ __launch_bounds__(256) void k_read16(uint32_t *dst, const uint4 *src,
     if (lane_id() == 0) dst[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
 
+// read-only streams shaped like the framing kernel's tile loads: every wave reads its own contiguous
+// 9216-byte chunk, 12 loads per lane.  mode 1: 16 bytes per lane per load (768 B of 1024 used: 12-byte lane
+// stride, overlapping);  mode 2: 12 bytes per lane (dwordx3);  mode 3: 16 bytes per lane, no overlap (12288 B).
+struct __attribute__((packed, aligned(4))) p_u4 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(1))) p_u3 { uint32_t v[3]; };
+template <int MODE>
+__global__ __launch_bounds__(256) void k_read_tiles(uint32_t *dst, const uint8_t *src, size_t n_tiles)
+{
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint32_t lane = lane_id();
+    uint32_t acc = 0;
+    if (MODE == 3) {
+        const uint8_t *b = src + t * 12288 + 16u * lane;
+#pragma unroll
+        for (int it = 0; it < 12; it++) { uint4 q = *reinterpret_cast<const uint4 *>(b + 1024u * it); acc ^= q.x ^ q.y ^ q.z ^ q.w; }
+    } else if (MODE == 2) {
+        const uint8_t *b = src + 3 + t * 9216 + 12u * lane;
+#pragma unroll
+        for (int it = 0; it < 12; it++) { p_u3 q = *reinterpret_cast<const p_u3 *>(b + 768u * it); acc ^= q.v[0] ^ q.v[1] ^ q.v[2]; }
+    } else {
+        const uint8_t *b = src + t * 9216 + 12u * lane;
+#pragma unroll
+        for (int it = 0; it < 12; it++) { p_u4 q = *reinterpret_cast<const p_u4 *>(b + 768u * it); acc ^= q.v[0] ^ q.v[1] ^ q.v[2] ^ q.v[3]; }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && acc == 0x12345u) dst[0] = acc;
+}
+
 }  // namespace
+
+extern "C" int slam_read_probe_dev(slam_ctx *ctx, void *scratch_dev, const void *src_dev, size_t n, int mode)
+{
+    if (!ctx || !scratch_dev || !src_dev) return SLAM_E_INVALID;
+    const size_t per = mode == 3 ? 12288 : 9216;
+    const size_t nt = (n - 64) / per;
+    dim3 grid((uint32_t)((nt + 3) / 4)), block(256);
+    if (mode == 3) { SLAM_LAUNCH(ctx, "read_tiles3", (k_read_tiles<3>), grid, block, (uint32_t *)scratch_dev, (const uint8_t *)src_dev, nt); }
+    else if (mode == 2) { SLAM_LAUNCH(ctx, "read_tiles2", (k_read_tiles<2>), grid, block, (uint32_t *)scratch_dev, (const uint8_t *)src_dev, nt); }
+    else { SLAM_LAUNCH(ctx, "read_tiles1", (k_read_tiles<1>), grid, block, (uint32_t *)scratch_dev, (const uint8_t *)src_dev, nt); }
+    return SLAM_OK;
+}
 
 extern "C" size_t slam_synth_text_len(uint32_t B, uint32_t N)
 {

@@ -7,6 +7,13 @@ constexpr int FRAME_RUN = 48;                    // data bytes owned by one lane
 constexpr int FRAME_TILE = 64 * FRAME_RUN;       // 3072 data bytes per wave tile
 constexpr int FRAME_TILE_DW = FRAME_TILE / 4 + 4;  // tile + 16 halo bytes, in dwords
 constexpr int FRAME_SUMM_WORDS = 11;             // one packed word per entry offset 0..10
+constexpr int FRAME_TPW = 4;                     // tiles each wave walks per launch
+
+struct frame_desc {             // prepared per frame: where its first token / byte is and how long it is
+    uint64_t off;               // from frame_src::base
+    uint32_t nb;                // data bytes
+    uint32_t n_src;             // source bytes from off
+};
 
 enum { SRC_TEXT3 = 0, SRC_RAW = 1, SRC_DEC = 2 };
 
@@ -16,7 +23,7 @@ struct frame_src {
     const uint32_t *len;        // device [F]
     const uint8_t *dec;         // device: bytes decoded by pass 1 (frame f at f*dec_stride), SRC_DEC only
     uint64_t dec_stride;
-    const uint32_t *stats;      // device: SLAM_STAT_NBYTES gives each frame's decoded length (SRC_DEC)
+    const frame_desc *fdesc;    // device [F], written by the prepare kernel
 };
 
 struct frame_ws {               // device scratch of the framing stage
@@ -26,8 +33,9 @@ struct frame_ws {               // device scratch of the framing stage
     uint8_t *dec;               // [F * dec_stride] decoded data bytes of text frames
     uint64_t dec_stride;
     static uint64_t dec_stride_for(uint32_t nt_max) { return (uint64_t)nt_max * FRAME_TILE + 256; }
-    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[4]);
-    void bind(uint8_t *base, const size_t off[4], uint32_t nt_max);
+    frame_desc *fdesc;          // [F]
+    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[5]);
+    void bind(uint8_t *base, const size_t off[5], uint32_t nt_max);
 };
 
 struct rows_out {               // decoded records, frame f at f*row_cap

@@ -19,3 +19,16 @@ for name, dst, src, traffic in (("copy", b, a, 2 * n), ("read", a, a, n)):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print(f"{name}: {traffic / dt / 1e12:.2f} TB/s ({dt * 1e3:.3f} ms per {n >> 20} MiB)")
+
+lib = c.lib
+lib.slam_read_probe_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+for mode in (1, 2, 3):
+    for _ in range(3):
+        c.check(lib.slam_read_probe_dev(c.h, C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, mode))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        c.check(lib.slam_read_probe_dev(c.h, C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, mode))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print(f"tile-shaped read mode {mode}: {n / dt / 1e12:.2f} TB/s")
