@@ -170,8 +170,7 @@ def main():
     if kern:
         # algorithmic bytes each kernel must move per frame (its own inputs + outputs, no re-reads)
         alg = {
-            "frame_summarize": 3.0 * nbytes + nbytes,        # text in, decoded bytes out
-            "frame_emit": nbytes + 11.0 * valid,             # decoded bytes in, records out
+            "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
             "rows_summarize": 6.0 * valid,                   # ue, flag, rss
             "rows_groups": 6.0 * valid,
             "rows_correct": 10.0 * valid + valid,            # flag, ue, rss, clk in; corrected-BS byte out

@@ -141,10 +141,16 @@ typedef struct slam_batch {
     double vmin, vmax;            /* NaN = autoscale                                              */
     const uint8_t *lut_dev;       /* [256*3]                                                      */
     int32_t tile_w, tile_h;
-    /* outputs; row arrays have row_cap entries per frame, frame f at offset f*row_cap */
-    uint32_t row_cap;             /* multiple of 16, >= max_text_len/33 + 2 (/11 for bytes)       */
+    /* outputs; row arrays have row_cap entries per frame, frame f at offset f*row_cap (16-byte aligned
+     * bases).  Decoded records are written tile by tile: the records that start in data bytes
+     * [t*SLAM_TILE_BYTES, (t+1)*SLAM_TILE_BYTES) of frame f, in order, occupy entries
+     * [t*SLAM_TILE_SLOTS, t*SLAM_TILE_SLOTS + tile_cnt_dev[f*T + t]) with T = slam_row_tiles(max_text_len,
+     * src_is_bytes); the other entries of a tile are unused.  Concatenating the tiles' used entries gives
+     * the reference's record list.  Corrected rows (kept_*) are dense. */
+    uint32_t row_cap;             /* multiple of 16, >= T * SLAM_TILE_SLOTS                       */
     uint8_t *flag_dev, *ue_dev, *bs_dev;        /* decoded records                               */
     uint32_t *rss_dev, *clk_dev;
+    uint32_t *tile_cnt_dev;       /* [F*T] records per tile (NULL: kept in the ctx workspace)     */
     uint8_t *kept_ue_dev, *kept_bs_dev;         /* corrected rows                                */
     uint32_t *kept_rss_dev, *kept_clk_dev;
     uint32_t *stats_dev;          /* [F*SLAM_STAT_WORDS], see SLAM_STAT_*                         */
@@ -152,6 +158,11 @@ typedef struct slam_batch {
     double *blurred_dev;          /* [F*n_axis*n_axis] blurred compact matrix, row stride n_aoa   */
     uint8_t *tile_dev;            /* [F*tile_h*tile_w*4]                                          */
 } slam_batch;
+
+#define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
+#define SLAM_TILE_SLOTS     276   /* entries reserved per tile in the decoded-record arrays        */
+/* Tiles per frame for frames of up to max_text_len text bytes (or data bytes when src_is_bytes). */
+uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 
 #define SLAM_STAT_WORDS      16
 #define SLAM_STAT_NBYTES      0   /* data bytes decoded from the text                            */
@@ -168,6 +179,8 @@ typedef struct slam_batch {
 #define SLAM_STAT_VMIN_HI    11
 #define SLAM_STAT_VMAX_LO    12
 #define SLAM_STAT_VMAX_HI    13
+#define SLAM_STAT_ROW_SLOTS  14   /* entries of the decoded-record arrays this frame spans         */
+#define SLAM_STAT_TWO_PASS   15   /* 1 = decoded by the two-pass kernels (entries then dense)      */
 
 /* Replaces, per frame, the chain main() -> _read_bytes -> _parse_groups
  * (serial_hex_to_excel_v3.py:153-154), process_excel_filtered's data path
@@ -189,6 +202,10 @@ int slam_synth_frames_dev(slam_ctx *ctx, uint8_t *text_dev, uint64_t frame_strid
 
 /* Device bandwidth probe used by the benchmark for the measured-copy ceiling: dst <- src, n bytes. */
 int slam_copy_probe_dev(slam_ctx *ctx, void *dst_dev, const void *src_dev, size_t n);
+/* Read-only probes shaped like the framing kernels' loads: every wave reads its own contiguous chunk of
+ * src (n bytes) with 12 loads per lane.  mode 1: 16-byte loads at a 12-byte lane stride; 2: 12-byte loads;
+ * 3: 16-byte loads at a 16-byte lane stride.  scratch_dev: at least 4 writable bytes. */
+int slam_read_probe_dev(slam_ctx *ctx, void *scratch_dev, const void *src_dev, size_t n, int mode);
 
 /* Timing of the kernels a ctx launched since slam_timing_reset: per kernel name, launches and
  * total milliseconds from HIP events recorded on the ctx's stream around each launch (only when

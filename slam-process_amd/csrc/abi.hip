@@ -440,6 +440,7 @@ extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *u
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memset(ctx->pinned, 0, SLAM_STAT_WORDS * 4);
     ctx->pinned[SLAM_STAT_VALID] = (uint32_t)n;
+    ctx->pinned[SLAM_STAT_ROW_SLOTS] = (uint32_t)n;
     if (explicit_bl) ctx->pinned[SLAM_STAT_BASELINES] = (uint32_t)bl_in_n;
     SLAM_TRY(h2d(ctx, stats, ctx->pinned, SLAM_STAT_WORDS * 4));
     if (explicit_bl && bl_in_n) {
@@ -588,8 +589,8 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[5], cw[16], rw[5];
-    uint32_t nt_max, bl_cap;
+    size_t fw[5], cw[16], rw[5], tc;
+    uint32_t nt_max, st_max, bl_cap;
     size_t total;
 };
 
@@ -597,10 +598,12 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
 {
     if (!bt || !bt->text_dev || !bt->text_off_dev || !bt->text_len_dev || !bt->stats_dev)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: text, offsets, lengths and stats are required");
-    if (bt->row_cap % 16 || (uint64_t)bt->row_cap < ((uint64_t)bt->max_text_len + (bt->src_is_bytes ? 0 : 1)) /
-                                                         (bt->src_is_bytes ? 11 : 33) + 2)
-        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: row_cap must be a multiple of 16 and >= max_text_len/33 + 2");
+    bp.st_max = slot_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
+    if (bt->row_cap % 16 || (uint64_t)bt->row_cap < (uint64_t)bp.st_max * SLOT_ROWS)
+        return slam_fail(ctx, SLAM_E_INVALID,
+                         "slam_batch: row_cap must be a multiple of 16 and >= slam_row_tiles(...) * SLAM_TILE_SLOTS");
     ws_plan p;
+    bp.tc = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
     bp.nt_max = frame_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
     bp.bl_cap = correct_ws::default_bl_cap(bt->row_cap);
     frame_ws::plan(p, bt->n_frames, bp.nt_max, bp.fw);
@@ -643,7 +646,11 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     cws.bind(b, bp.cw, bp.bl_cap);
     render_ws rws;
     rws.bind(b, bp.rw);
-    rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
+    uint32_t *tile_cnt = bt->tile_cnt_dev ? bt->tile_cnt_dev : (uint32_t *)(b + bp.tc);
+    rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap, tile_cnt, bp.st_max};
+    if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
+         (uintptr_t)bt->clk_dev) & 15u)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays must be 16-byte aligned");
     if (stages & 1u) {
         SLAM_HIP(ctx, hipMemsetAsync(bt->stats_dev, 0, (size_t)F * SLAM_STAT_WORDS * 4, ctx->stream));
         frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev, nullptr, 0, nullptr};
@@ -651,7 +658,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
                               rows, bt->stats_dev));
     }
     if (stages & 2u) {
-        rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap};
+        rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap,
+                                        tile_cnt, bp.st_max};
         kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev};
         if (bt->cycle <= 0 || bt->cycle > (1 << 30)) return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");
         correct_params prm;

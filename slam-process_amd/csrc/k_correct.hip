@@ -36,18 +36,61 @@ __device__ __forceinline__ void load4(const T *p, T v[4])
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
 
-// boundary / baseline bits of the 4 rows [i0, i0+4) of a frame with n rows
+// The rows of one frame as the row kernels walk them: n entries, of which some may be unused slots
+// (slotted layout: the records of framing tile t sit at the front of entries [t*SLOT_ROWS, (t+1)*SLOT_ROWS)).
+struct frame_span {
+    uint32_t n;                 // entries to walk
+    const uint32_t *cnt;        // records per framing tile, or nullptr when every entry is a row
+};
+constexpr uint32_t NO_ROW = 0xFFFFFFFFu;
+
 template <typename T8, typename T32>
-__device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb, uint32_t i0, uint32_t n,
-                                         int mode, uint32_t *bound, uint32_t *base)
+__device__ __forceinline__ frame_span span_of(const rows_in_t<T8, T32> &in, uint32_t f, const uint32_t *stats)
 {
-    // mode bit 0: one group (only row 0 starts a group); bit 1: baselines are given, detect none
+    frame_span s;
+    s.n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
+    s.cnt = in.slot_cnt ? in.slot_cnt + (size_t)f * in.slot_stride : nullptr;
+    return s;
+}
+
+// Which of the entries [i0, i0+4) are rows (bit k; always a prefix of the four since i0 % 4 == 0 and
+// SLOT_ROWS % 4 == 0), and the index of the last row before i0 (NO_ROW if there is none).
+__device__ __forceinline__ uint32_t live4(const frame_span &s, uint32_t i0, uint32_t *prev)
+{
+    *prev = NO_ROW;
+    if (i0 >= s.n) return 0;
+    if (!s.cnt) {
+        if (i0) *prev = i0 - 1;
+        const uint32_t left = s.n - i0;
+        return left >= 4 ? 0xFu : (1u << left) - 1u;
+    }
+    const uint32_t t = i0 / SLOT_ROWS, k0 = i0 - t * SLOT_ROWS, c = s.cnt[t];
+    if (k0 > 0) {
+        *prev = i0 - 1;                             // a row whenever any of the four is
+    } else {
+        for (uint32_t tt = t; tt > 0;) {
+            --tt;
+            const uint32_t cc = s.cnt[tt];
+            if (cc) { *prev = tt * SLOT_ROWS + cc - 1; break; }
+        }
+    }
+    if (c <= k0) return 0;
+    return c - k0 >= 4 ? 0xFu : (1u << (c - k0)) - 1u;
+}
+
+// boundary / baseline bits of the 4 entries [i0, i0+4) of a frame; *live as live4, *prev the row before i0
+template <typename T8, typename T32>
+__device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb, const frame_span &sp, uint32_t i0,
+                                         int mode, uint32_t *bound, uint32_t *base, uint32_t *live, uint32_t *prev)
+{
+    // mode bit 0: one group (only the first row starts a group); bit 1: baselines are given, detect none
     *bound = 0;
     *base = 0;
-    if (i0 >= n) return;
+    *live = live4(sp, i0, prev);
+    if (!*live) return;
     const bool one_group = mode & 1;
     if (mode & 2) {
-        if (i0 == 0) *bound = 1;
+        if (*prev == NO_ROW) *bound = 1;
         return;
     }
     T8 ue[4], fl[4];
@@ -57,19 +100,20 @@ __device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb
     load4(in.rss + fb + i0, rs);
     T8 pue = 0, pfl = 0;
     T32 prs = 0;
-    if (i0 > 0) {
-        pue = in.ue[fb + i0 - 1];
-        pfl = in.flag[fb + i0 - 1];
-        prs = in.rss[fb + i0 - 1];
+    bool first = *prev == NO_ROW;
+    if (!first) {
+        pue = in.ue[fb + *prev];
+        pfl = in.flag[fb + *prev];
+        prs = in.rss[fb + *prev];
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint32_t i = i0 + k;
-        if (i < n) {
-            bool b = (i == 0) || (!one_group && pue > ue[k]);
+        if ((*live >> k) & 1u) {
+            bool b = first || (!one_group && pue > ue[k]);
             bool bl = !b && fl[k] == 1 && pfl == 0 && rs[k] == prs;
             *bound |= (uint32_t)b << k;
             *base |= (uint32_t)bl << k;
+            first = false;
         }
         pue = ue[k]; pfl = fl[k]; prs = rs[k];
     }
@@ -82,9 +126,9 @@ __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, u
 {
     __shared__ uint32_t sh[8];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
-    uint32_t bound, base;
-    row_bits(in, (size_t)f * in.row_cap, tile * ROWS_PER_BLOCK + tid * 4, n, one_group, &bound, &base);
+    const frame_span sp = span_of(in, f, stats);
+    uint32_t bound, base, live, prev;
+    row_bits(in, (size_t)f * in.row_cap, sp, tile * ROWS_PER_BLOCK + tid * 4, one_group, &bound, &base, &live, &prev);
     uint32_t cb = wave_sum(__popc(bound)), cl = wave_sum(__popc(base));
     if (lane_id() == 0) { sh[tid >> 6] = cb; sh[4 + (tid >> 6)] = cl; }
     __syncthreads();
@@ -102,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, ui
 {
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     const uint32_t nt = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     uint32_t ca = 0, cb = 0;
     for (uint32_t seg = 0; seg < nt; seg += 1024) {
@@ -141,12 +185,12 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
 {
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const frame_span sp = span_of(in, f, stats);
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
-    if (tile * ROWS_PER_BLOCK >= n) return;
+    if (tile * ROWS_PER_BLOCK >= sp.n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    uint32_t bound, base;
-    row_bits(in, fb, i0, n, one_group, &bound, &base);
+    uint32_t bound, base, live, prev;
+    row_bits(in, fb, sp, i0, one_group, &bound, &base, &live, &prev);
     uint32_t tot;
     uint32_t packed = __popc(bound) | (__popc(base) << 16);       // both counts fit 16 bits per block
     uint32_t ex = block_excl_scan(packed, sh, &tot);
@@ -157,14 +201,14 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t i = i0 + k;
-        if (i >= n) break;
+        if (!((live >> k) & 1u)) break;
         if ((bound >> k) & 1u) {
             ws.grp_row[gs + g] = i;
             ws.grp_bl[gs + g] = j;
             g++;
         }
         if ((base >> k) & 1u) {
-            ws.bl_clk[bsb + j] = (int32_t)in.clk[fb + i - 1];
+            ws.bl_clk[bsb + j] = (int32_t)in.clk[fb + (k ? i - 1 : prev)];
             ws.bl_bs[bsb + j] = (int32_t)in.bs[fb + i];
             ws.bl_gid[bsb + j] = g - 1;
             j++;
@@ -342,12 +386,13 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     __shared__ uint4 t_pay[TAB_CAP];
     __shared__ uint32_t shk[4];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const frame_span sp = span_of(in, f, stats);
+    const uint32_t n = sp.n;
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
     if (tile * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    uint32_t bound, base;
-    row_bits(in, fb, i0, n, one_group, &bound, &base);
+    uint32_t bound, base, live, prev;
+    row_bits(in, fb, sp, i0, one_group, &bound, &base, &live, &prev);
     uint32_t tot;
     const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
     const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     T32 ck[4] = {0, 0, 0, 0};
     uint32_t gi[4], q1[4], r1[4];
     TC res[4];
-    if (i0 < n) {
+    if (live) {
         load4(in.flag + fb + i0, fl);
         load4(in.clk + fb + i0, ck);
     }
@@ -370,7 +415,7 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
             if ((bound >> k) & 1u) g++;
             gi[k] = g - 1;
             res[k] = corr_none<TC>::v;
-            if (i0 + k >= n) fl[k] = 1;                       // rows past the end take no part
+            if (!((live >> k) & 1u)) fl[k] = 1;               // entries that are not rows take no part
             phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
         }
     }
@@ -429,7 +474,7 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 {
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID];
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
     if (tile * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;

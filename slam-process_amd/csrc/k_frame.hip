@@ -16,6 +16,16 @@
 // depends on the tile's entry offset.  Pass 1 stores, per tile and entry offset, (exit offset,
 // records, discards); a per-frame scan picks each tile's entry and output offset; pass 2 emits.
 // Non-synchronising data (adversarial byte patterns) takes a slower chained path, same results.
+//
+// Single-pass form (batched pipeline).  Inside a record no other position can start a record (only byte 1
+// has tag 00 and only byte 2 has tag 11, and a flag byte is followed by tags 00, 11), so two scan heads less
+// than 11 apart meet within 21 bytes: one 48-byte run before a tile pins the scan position at the tile's
+// start whatever happened earlier.  k_frame_onepass gives every wave such a look-behind run (lane 0) plus 63
+// runs of its own, needs nothing from other tiles, and writes each tile's records into the tile's own
+// block of row slots, so no output offsets have to be scanned either.  A frame with a look-behind run that does
+// not pin the position (only possible next to the end of the data) is redone by the two-pass kernels.
+
+#include <stdlib.h>
 
 #include "pipeline.hpp"
 
@@ -34,7 +44,8 @@ struct src_view {
 // Per-frame source description, prepared once per batch so the tile kernels start with one 16-byte load
 // instead of a chain of dependent reads (offset table -> text prefix).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_frame_prepare(frame_src s, uint32_t F, frame_desc *fd, uint32_t *stats)
+__global__ __launch_bounds__(256) void k_frame_prepare(frame_src s, uint32_t F, frame_desc *fd, uint32_t *stats,
+                                                        int slotted, int force_two_pass)
 {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
@@ -58,6 +69,10 @@ __global__ __launch_bounds__(256) void k_frame_prepare(frame_src s, uint32_t F, 
     fd[f] = d;
     stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES] = d.nb;
     if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
+    if (slotted) {
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS] = (d.nb + SLOT_TILE - 1) / SLOT_TILE * SLOT_ROWS;
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS] = force_two_pass ? 1u : 0u;
+    }
 }
 
 template <int MODE>
@@ -347,10 +362,12 @@ __device__ __forceinline__ uint32_t resolve_entries(const run_masks &m, uint32_t
 // Each wave owns its LDS tile and walks FRAME_TPW tiles; waves never wait for each other.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t nt_max, uint32_t *summ,
-                                                          uint32_t *stats, uint8_t *dec, uint64_t dec_stride)
+                                                          uint32_t *stats, uint8_t *dec, uint64_t dec_stride,
+                                                          int gated)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    if (gated && !stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS]) return;
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     uint32_t *tile = lds[wv];
@@ -424,12 +441,14 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
 
 // ---- per-frame scan over tiles --------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_frame_scan(const uint32_t *summ, uint32_t nt_max,
-                                                      uint8_t *tile_entry, uint32_t *tile_off, uint32_t *stats)
+                                                      uint8_t *tile_entry, uint32_t *tile_off, uint32_t *stats,
+                                                      int gated, uint32_t *slot_cnt, uint32_t slot_stride)
 {
     __shared__ uint8_t ent[1025];
     __shared__ uint32_t sh[17];
     __shared__ uint32_t pending;
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    if (gated && !stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS]) return;
     const uint32_t nb = stats[f * SLAM_STAT_WORDS + SLAM_STAT_NBYTES];
     const uint32_t nt = (nb + FRAME_TILE - 1) / FRAME_TILE;
     uint32_t carry_e = 0, carry_v = 0, carry_d = 0;
@@ -478,16 +497,25 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const uint32_t *summ, uint3
     if (tid == 0) {
         stats[f * SLAM_STAT_WORDS + SLAM_STAT_VALID] = carry_v;
         stats[f * SLAM_STAT_WORDS + SLAM_STAT_DISCARDED] = carry_d;
+        stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS] =
+            slot_cnt ? (carry_v + SLOT_ROWS - 1) / SLOT_ROWS * SLOT_ROWS : carry_v;
+    }
+    if (slot_cnt) {       // dense rows described as slots: full tiles, then a partial one
+        for (uint32_t t = tid; t < slot_stride; t += 1024) {
+            const uint64_t lo = (uint64_t)t * SLOT_ROWS;
+            slot_cnt[(size_t)f * slot_stride + t] = lo >= carry_v ? 0u : (uint32_t)min((uint64_t)SLOT_ROWS, carry_v - lo);
+        }
     }
 }
 
 // ---- pass 2: emit records ---------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_max, const uint8_t *tile_entry,
-                                                     const uint32_t *tile_off, rows_out out)
+                                                     const uint32_t *tile_off, rows_out out, const uint32_t *gate)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    if (gate && !gate[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS]) return;
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     uint32_t bad = 0;
@@ -530,6 +558,115 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
     }
 }
 
+// ---- single pass: text -> records in the tile's own row slots -----------------------------------------
+constexpr int STAGE_DW = 2 * SLOT_ROWS + 3 * (SLOT_ROWS / 4) + 1;      // clk, rss dwords; flag, ue, bs bytes; pad to 16 B
+static_assert(STAGE_DW % 4 == 0, "staging areas stay 16-byte aligned");
+
+// The one-pass tile t holds data bytes [t*SLOT_TILE - 48, t*SLOT_TILE + SLOT_TILE + 16): lane 0's run is the
+// look-behind run (the bytes before the data are taken as zero for t == 0).
+template <int MODE>
+__device__ __forceinline__ void fill_slot_tile(uint32_t *tile, const src_view &sv, uint32_t t, uint32_t *bad)
+{
+    if (t > 0) {
+        fill_tile<MODE, true>(tile, sv, t * SLOT_TILE - FRAME_RUN, bad, nullptr);
+        return;
+    }
+    for (uint32_t d = lane_id(); d < (uint32_t)FRAME_TILE_DW; d += 64)
+        tile[d] = d < FRAME_RUN / 4 ? 0u : load_data_dword<MODE, true>(sv, 4u * (d - FRAME_RUN / 4), bad);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4][STAGE_DW];
+    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    if (st[SLAM_STAT_TWO_PASS]) return;
+    const src_view sv = resolve_src<MODE>(src, f);
+    const uint32_t nt = (sv.nb + SLOT_TILE - 1) / SLOT_TILE;
+    uint32_t *tile = lds[wv];
+    uint32_t *stg = stage[wv];
+    uint8_t *stg8 = reinterpret_cast<uint8_t *>(stg + 2 * SLOT_ROWS);
+    uint32_t bad = 0, accv = 0, accd = 0, unsync = 0;
+    for (uint32_t j = 0; j < FRAME_TPW; j++) {
+        const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+        if (t >= nt) break;
+        fill_slot_tile<MODE>(tile, sv, t, &bad);
+        wave_lds_sync();
+
+        run_masks m = make_masks(tile, (int64_t)sv.nb - ((int64_t)t * SLOT_TILE - FRAME_RUN) - (int64_t)lane * FRAME_RUN);
+        uint32_t x;
+        {
+            const uint64_t exits = closure(0x7FFull, m) >> FRAME_RUN;
+            x = __popcll(exits) == 1 ? (uint32_t)__builtin_ctzll(exits) : UNK;
+        }
+        if (lane == 0) {
+            if (t == 0) x = 0;                       // the scan starts at data byte 0
+            else if (x == UNK) unsync = 1;
+        }
+        uint32_t ex;
+        const uint32_t entry = resolve_entries(m, x, 0u, &ex);
+        const uint64_t v = closure(1ull << entry, m);
+        uint64_t starts = lane ? (v & m.ok) : 0ull;  // the look-behind run's records belong to the tile before
+        const uint32_t cnt = __popcll(starts);
+        const uint32_t inc = wave_incl_scan(cnt);
+        accd += lane ? count_disc(v, m) : 0u;
+        uint32_t li = inc - cnt;
+        const uint32_t lane_byte = lane * FRAME_RUN;
+        while (starts) {
+            uint32_t p = (uint32_t)__builtin_ctzll(starts);
+            starts &= starts - 1;
+            uint32_t off = lane_byte + p, sh = off & 3u, wi = off >> 2;
+            uint32_t w0 = tile[wi], w1 = tile[wi + 1], w2 = tile[wi + 2], w3 = tile[wi + 3];
+            uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            uint32_t d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            uint32_t d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+            stg[li] = ((d0 >> 24) & 63u) | ((d1 & 63u) << 6) | (((d1 >> 8) & 63u) << 12) |
+                      (((d1 >> 16) & 63u) << 18) | (((d1 >> 24) & 63u) << 24);
+            stg[SLOT_ROWS + li] = (d2 & 63u) | (((d2 >> 8) & 63u) << 6) | (((d2 >> 16) & 63u) << 12);
+            stg8[li] = (uint8_t)((m.cc >> p) & 1u);
+            stg8[SLOT_ROWS + li] = (uint8_t)((d0 >> 8) & 63u);
+            stg8[2 * SLOT_ROWS + li] = (uint8_t)((d0 >> 16) & 63u);
+            li++;
+        }
+        wave_lds_sync();
+        // whole slot block of the tile, full-width stores (slots past the tile's count hold leftovers)
+        {
+            constexpr uint32_t Q = SLOT_ROWS / 4;                    // 69 16-byte pieces per dword column
+            const size_t rb = (size_t)f * out.row_cap + (size_t)t * SLOT_ROWS;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(stg);
+            uint4 *gc = reinterpret_cast<uint4 *>(out.clk + rb), *gr = reinterpret_cast<uint4 *>(out.rss + rb);
+            uint32_t *gf = reinterpret_cast<uint32_t *>(out.flag + rb), *gu = reinterpret_cast<uint32_t *>(out.ue + rb),
+                     *gb = reinterpret_cast<uint32_t *>(out.bs + rb);
+            const uint32_t *s1 = stg + 2 * SLOT_ROWS;
+            gc[lane] = s4[lane];
+            gr[lane] = s4[Q + lane];
+            gf[lane] = s1[lane];
+            gu[lane] = s1[Q + lane];
+            gb[lane] = s1[2 * Q + lane];
+            if (lane < Q - 64) {
+                gc[64 + lane] = s4[64 + lane];
+                gr[64 + lane] = s4[Q + 64 + lane];
+                gf[64 + lane] = s1[64 + lane];
+                gu[64 + lane] = s1[Q + 64 + lane];
+                gb[64 + lane] = s1[2 * Q + 64 + lane];
+            }
+            if (lane == 63) out.slot_cnt[(size_t)f * out.slot_stride + t] = inc;
+        }
+        accv += cnt;
+        wave_lds_sync();
+    }
+    accv = wave_sum(accv);
+    accd = wave_sum(accd);
+    if (lane == 0) {
+        if (accv) atomicAdd(st + SLAM_STAT_VALID, accv);
+        if (accd) atomicAdd(st + SLAM_STAT_DISCARDED, accd);
+    }
+    if (bad) st[SLAM_STAT_NOT_STRICT] = 1;
+    if (unsync) st[SLAM_STAT_TWO_PASS] = 1;
+}
+
 }  // namespace
 
 uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
@@ -537,6 +674,18 @@ uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
     uint64_t nb = mode == SRC_TEXT3 ? ((uint64_t)max_src_len + 1) / 3 : max_src_len;
     uint32_t nt = (uint32_t)((nb + FRAME_TILE - 1) / FRAME_TILE);
     return nt ? nt : 1;
+}
+
+uint32_t slot_tiles_for(int mode, uint32_t max_src_len)
+{
+    uint64_t nb = mode == SRC_TEXT3 ? ((uint64_t)max_src_len + 1) / 3 : max_src_len;
+    uint32_t nt = (uint32_t)((nb + SLOT_TILE - 1) / SLOT_TILE);
+    return nt ? nt : 1;
+}
+
+extern "C" uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes)
+{
+    return slot_tiles_for(src_is_bytes ? SRC_RAW : SRC_TEXT3, max_text_len);
 }
 
 void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[5])
@@ -561,34 +710,51 @@ void frame_ws::bind(uint8_t *b, const size_t off[5], uint32_t nt_max)
 int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, uint32_t max_src_len,
                  const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats)
 {
-    (void)max_src_len;
     if (F == 0) return SLAM_OK;
     dim3 grid((nt_max + 4 * FRAME_TPW - 1) / (4 * FRAME_TPW), F), block(256);
     frame_src src = src_in;
     src.dec = ws.dec;
     src.dec_stride = ws.dec_stride;
     src.fdesc = ws.fdesc;
+    const int slotted = out.slot_cnt != nullptr;
+    const char *force_env = getenv("SLAMHIP_FORCE_TWO_PASS");      // test hook: every frame takes the two-pass kernels
+    const int force = slotted && force_env && force_env[0] == '1';
     if (mode == SRC_TEXT3) {
-        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_TEXT3>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc, stats);
+        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_TEXT3>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc,
+                    stats, slotted, force);
     } else {
-        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_RAW>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc, stats);
+        SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_RAW>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc,
+                    stats, slotted, force);
     }
+    if (slotted) {
+        const uint32_t st_max = slot_tiles_for(mode, max_src_len);
+        if (out.slot_stride < st_max || (uint64_t)out.row_cap < (uint64_t)st_max * SLOT_ROWS)
+            return slam_fail(ctx, SLAM_E_CAPACITY, "row arrays too small for the tile-slotted layout");
+        dim3 g1((st_max + 4 * FRAME_TPW - 1) / (4 * FRAME_TPW), F);
+        if (mode == SRC_TEXT3) {
+            SLAM_LAUNCH(ctx, "frame_onepass", (k_frame_onepass<SRC_TEXT3>), g1, block, src, out, stats);
+        } else {
+            SLAM_LAUNCH(ctx, "frame_onepass", (k_frame_onepass<SRC_RAW>), g1, block, src, out, stats);
+        }
+    }
+    // two passes: every frame (dense layout) or only the frames the single pass flagged
     if (mode == SRC_TEXT3) {
         // pass 1 reads the text once, validates it and leaves the decoded bytes; pass 2 reads bytes
         SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats,
-                    ws.dec, ws.dec_stride);
+                    ws.dec, ws.dec_stride, slotted);
     } else {
         SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_RAW>), grid, block, src, nt_max, ws.summ, stats,
-                    (uint8_t *)nullptr, (uint64_t)0);
+                    (uint8_t *)nullptr, (uint64_t)0, slotted);
     }
     SLAM_LAUNCH(ctx, "frame_scan", k_frame_scan, dim3(F), dim3(1024), ws.summ, nt_max, ws.tile_entry,
-                ws.tile_off, stats);
+                ws.tile_off, stats, slotted, out.slot_cnt, out.slot_stride);
+    const uint32_t *gate = slotted ? stats : nullptr;
     if (mode == SRC_TEXT3) {
         SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_DEC>), grid, block, src, nt_max, ws.tile_entry,
-                    ws.tile_off, out);
+                    ws.tile_off, out, gate);
     } else {
         SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_RAW>), grid, block, src, nt_max, ws.tile_entry,
-                    ws.tile_off, out);
+                    ws.tile_off, out, gate);
     }
     return SLAM_OK;
 }

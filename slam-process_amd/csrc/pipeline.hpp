@@ -8,6 +8,10 @@ constexpr int FRAME_TILE = 64 * FRAME_RUN;       // 3072 data bytes per wave til
 constexpr int FRAME_TILE_DW = FRAME_TILE / 4 + 4;  // tile + 16 halo bytes, in dwords
 constexpr int FRAME_SUMM_WORDS = 11;             // one packed word per entry offset 0..10
 constexpr int FRAME_TPW = 4;                     // tiles each wave walks per launch
+// single-pass framing: a wave's tile is one look-behind run + 63 runs of its own
+constexpr int SLOT_TILE = 63 * FRAME_RUN;        // 3024 data bytes whose records one wave emits
+constexpr int SLOT_ROWS = SLAM_TILE_SLOTS;       // row slots per such tile: ceil(3024 / 11) = 275, rounded up to 4
+static_assert(SLOT_TILE == SLAM_TILE_BYTES && SLOT_ROWS % 4 == 0 && SLOT_ROWS * 11 >= SLOT_TILE + 10, "slot geometry");
 
 struct frame_desc {             // prepared per frame: where its first token / byte is and how long it is
     uint64_t off;               // from frame_src::base
@@ -38,16 +42,26 @@ struct frame_ws {               // device scratch of the framing stage
     void bind(uint8_t *base, const size_t off[5], uint32_t nt_max);
 };
 
-struct rows_out {               // decoded records, frame f at f*row_cap
+// Decoded records, frame f at f*row_cap.  Two layouts:
+//   dense   (slot_cnt == nullptr): records 0..VALID-1 in order;
+//   slotted (slot_cnt != nullptr): the records that start in data bytes [t*SLOT_TILE, (t+1)*SLOT_TILE) occupy
+//           slots [t*SLOT_ROWS, t*SLOT_ROWS + slot_cnt[f*slot_stride + t]); the rest of a tile's slots is unused.
+struct rows_out {
     uint8_t *flag, *ue, *bs;
     uint32_t *rss, *clk;
     uint32_t row_cap;
+    uint32_t *slot_cnt = nullptr;
+    uint32_t slot_stride = 0;
 };
 
 // Decode F frames: source -> records + stats words NBYTES / NOT_STRICT / VALID / DISCARDED.
+// out.slot_cnt == nullptr: two passes, dense rows.  Otherwise one pass over the source into the slotted layout
+// (frames whose look-behind run does not pin the scan position are redone by the two-pass kernels and
+// described as full slots); stats also gets ROW_SLOTS and TWO_PASS.
 int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t max_src_len,
                  const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats);
 uint32_t frame_tiles_for(int mode, uint32_t max_src_len);
+uint32_t slot_tiles_for(int mode, uint32_t max_src_len);
 
 // ---- correction ----------------------------------------------------------------------------------
 constexpr int ROWS_PER_BLOCK = 1024;             // 256 threads x 4 rows
@@ -57,6 +71,8 @@ struct rows_in_t {
     const T8 *flag, *ue, *bs;
     const T32 *rss, *clk;
     uint32_t row_cap;           // per-frame stride
+    const uint32_t *slot_cnt = nullptr;   // slotted layout (see rows_out); nullptr = dense
+    uint32_t slot_stride = 0;
 };
 
 template <typename T8, typename T32>

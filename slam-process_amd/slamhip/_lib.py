@@ -18,13 +18,15 @@ LIB_PATH = os.path.join(_HERE, "libslamhip.so")
 OK, E_INVALID, E_HIP, E_CAPACITY, E_EMPTY, E_ALLNAN, E_RANGE = 0, -1, -2, -3, -4, -5, -6
 STAT_WORDS = 16
 (STAT_NBYTES, STAT_NOT_STRICT, STAT_VALID, STAT_DISCARDED, STAT_GROUPS, STAT_BASELINES, STAT_KEPT,
- STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI) = range(14)
+ STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI,
+ STAT_ROW_SLOTS, STAT_TWO_PASS) = range(16)
+TILE_BYTES, TILE_SLOTS = 3024, 276
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_sync", "slam_last_error", "slam_version",
     "slam_hex_unpack", "slam_parse_records", "slam_parse_text", "slam_correct", "slam_pivot_mean",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_reserve_workspace",
-    "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev",
+    "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
 
@@ -47,7 +49,7 @@ class Batch(C.Structure):
         ("lut_dev", C.c_void_p), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("row_cap", C.c_uint32),
         ("flag_dev", C.c_void_p), ("ue_dev", C.c_void_p), ("bs_dev", C.c_void_p),
-        ("rss_dev", C.c_void_p), ("clk_dev", C.c_void_p),
+        ("rss_dev", C.c_void_p), ("clk_dev", C.c_void_p), ("tile_cnt_dev", C.c_void_p),
         ("kept_ue_dev", C.c_void_p), ("kept_bs_dev", C.c_void_p),
         ("kept_rss_dev", C.c_void_p), ("kept_clk_dev", C.c_void_p),
         ("stats_dev", C.c_void_p), ("matrix_dev", C.c_void_p), ("blurred_dev", C.c_void_p),
@@ -101,12 +103,15 @@ def load() -> C.CDLL:
         lib.slam_synth_text_len.restype = sz
         lib.slam_synth_frames_dev.argtypes = [vp, vp, u64, u32, u32, u32, u32, u64]
         lib.slam_copy_probe_dev.argtypes = [vp, vp, vp, sz]
+        lib.slam_read_probe_dev.argtypes = [vp, vp, vp, sz, C.c_int]
+        lib.slam_row_tiles.argtypes = [u32, u32]
+        lib.slam_row_tiles.restype = u32
         lib.slam_timing_enable.argtypes = [vp, C.c_int]
         lib.slam_timing_reset.argtypes = [vp]
         lib.slam_timing_read.argtypes = [vp, vp, vp, vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len"):
+            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len", "slam_row_tiles"):
                 fn.restype = C.c_int
         _lib = lib
         return lib

@@ -48,8 +48,8 @@ class FramePipeline:
         self.ctx = _lib.ctx(device)
         self.F = int(max_frames)
         self.max_text_len = int(max_text_len)
-        per = 11 if src_is_bytes else 33
-        self.row_cap = ((self.max_text_len // per + 2 + 15) // 16) * 16
+        self.row_tiles = int(self.ctx.lib.slam_row_tiles(self.max_text_len, 1 if src_is_bytes else 0))
+        self.row_cap = ((self.row_tiles * _lib.TILE_SLOTS + 15) // 16) * 16
         self.tile_w, self.tile_h = int(tile_w), int(tile_h)
         b2a, angles = ops.axis_from_mapping(mapping if mapping is not None else default_mapping())
         self.n_axis = len(angles)
@@ -64,6 +64,7 @@ class FramePipeline:
         self.bs = torch.empty(F * rc, dtype=u8, device=d)
         self.rss = torch.empty(F * rc, dtype=u32, device=d)
         self.clk = torch.empty(F * rc, dtype=u32, device=d)
+        self.tile_cnt = torch.zeros(F * self.row_tiles, dtype=u32, device=d)
         self.k_ue = torch.empty(F * rc, dtype=u8, device=d)
         self.k_bs = torch.empty(F * rc, dtype=u8, device=d)
         self.k_rss = torch.empty(F * rc, dtype=u32, device=d)
@@ -93,6 +94,7 @@ class FramePipeline:
         bt.row_cap = rc
         bt.flag_dev, bt.ue_dev, bt.bs_dev = self.flag.data_ptr(), self.ue.data_ptr(), self.bs.data_ptr()
         bt.rss_dev, bt.clk_dev = self.rss.data_ptr(), self.clk.data_ptr()
+        bt.tile_cnt_dev = self.tile_cnt.data_ptr()
         bt.kept_ue_dev, bt.kept_bs_dev = self.k_ue.data_ptr(), self.k_bs.data_ptr()
         bt.kept_rss_dev, bt.kept_clk_dev = self.k_rss.data_ptr(), self.k_clk.data_ptr()
         bt.stats_dev = self.stats.data_ptr()
@@ -137,11 +139,19 @@ class FramePipeline:
         return self.stats.cpu().numpy().view(np.uint32).reshape(self.F, _lib.STAT_WORDS)[: self.bt.n_frames]
 
     def frame_rows(self, f: int, st: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+        """Decoded records of frame f in order (the used entries of its tiles, concatenated)."""
         st = self.stats_host() if st is None else st
-        n, rc = int(st[f, _lib.STAT_VALID]), self.row_cap
-        sl = slice(f * rc, f * rc + n)
-        return dict(flag=self.flag[sl].cpu().numpy(), ue=self.ue[sl].cpu().numpy(), bs=self.bs[sl].cpu().numpy(),
-                    rss=self.rss[sl].cpu().numpy().view(np.uint32), clk=self.clk[sl].cpu().numpy().view(np.uint32))
+        rc, T, S = self.row_cap, self.row_tiles, _lib.TILE_SLOTS
+        span = int(st[f, _lib.STAT_ROW_SLOTS])
+        cnt = self.tile_cnt[f * T:f * T + span // S].to(torch.int64)
+        use = (torch.arange(S, device=self.dev)[None, :] < cnt[:, None]).reshape(-1)
+        sl = slice(f * rc, f * rc + span)
+        out = dict(flag=self.flag[sl][use].cpu().numpy(), ue=self.ue[sl][use].cpu().numpy(),
+                   bs=self.bs[sl][use].cpu().numpy(), rss=self.rss[sl][use].cpu().numpy().view(np.uint32),
+                   clk=self.clk[sl][use].cpu().numpy().view(np.uint32))
+        if len(out["flag"]) != int(st[f, _lib.STAT_VALID]):
+            raise RuntimeError("tile counts and the frame's record count disagree")
+        return out
 
     def frame_kept(self, f: int, st: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
         st = self.stats_host() if st is None else st

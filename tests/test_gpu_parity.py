@@ -284,12 +284,17 @@ def test_synth_device_matches_numpy():
         assert np.array_equal(host[i * stride:i * stride + tl], exp)
 
 
+@pytest.mark.parametrize("two_pass", [False, True])
 @pytest.mark.parametrize("shape", [(8, 256, 3), (16, 1024, 2), (4, 4096, 2)])
-def test_batched_pipeline_against_oracle(mapping, lut, shape):
+def test_batched_pipeline_against_oracle(mapping, lut, shape, two_pass, monkeypatch):
     import torch
     from slamhip import synth
     from slamhip.pipeline import FramePipeline, synth_frames
     B, N, F = shape
+    if two_pass:                       # every frame through the fallback the single-pass kernel hands over to
+        monkeypatch.setenv("SLAMHIP_FORCE_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("SLAMHIP_FORCE_TWO_PASS", raising=False)
     tl = synth.text_len(B, N)
     stride = ((tl + 255) // 256) * 256
     text = synth_frames(F, B, N)
@@ -300,6 +305,7 @@ def test_batched_pipeline_against_oracle(mapping, lut, shape):
     for f in range(F):
         by = synth.make_frame_bytes(B, N, f)
         assert st[f, 0] == len(by) and st[f, 1] == 0
+        assert int(st[f, 15]) == (1 if two_pass else 0)
         rows_o, v, d = O.parse_groups(by)
         assert (int(st[f, 2]), int(st[f, 3])) == (v, d)
         rows = pipe.frame_rows(f, st)
@@ -322,3 +328,61 @@ def test_batched_pipeline_against_oracle(mapping, lut, shape):
         r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=128)
         assert (lo, hi) == (r["vmin"], r["vmax"])
         assert np.array_equal(pipe.frame_tile(f), r["tile"])
+
+
+def _hostile_streams():
+    """Byte streams that stress the resynchronising scan: flag bytes everywhere, records cut by the end of the
+    data at every offset around a tile edge, long stretches without any record."""
+    rng = np.random.default_rng(77)
+    rec = lambda fl, ue, bs, clk, rss: bytes([0xCC if fl else 0x33, ue & 63, 0xC0 | (bs & 63)] +
+                                             [0x40 | ((clk >> (6 * j)) & 63) for j in range(5)] +
+                                             [0x80 | ((rss >> (6 * j)) & 63) for j in range(3)])
+    out = []
+    good = b"".join(rec(i & 1, 0x33, 0x0C, 1563 + 61000 * i, 20000 + i) for i in range(900))   # UE byte 0x33, BS byte 0xCC
+    for cut in list(range(3024 - 60, 3024 + 70, 7)) + [6048 - 5, 6048, 6048 + 5]:
+        out.append(good[:cut])
+    out.append(bytes([0x33]) * 7000)                                   # flag bytes only
+    out.append(bytes([0xCC, 0x33]) * 3500)
+    out.append(bytes(rng.integers(0, 256, 9000, dtype=np.uint8)))      # noise
+    out.append(bytes(rng.choice(np.frombuffer(b"\x33\xcc\x00\xc0\x40\x80", np.uint8), 9000)))
+    out.append(b"\x00" * 4000 + good[:3000] + b"\x7f" * 3100 + good[:5000])  # record-free stretches longer than a tile
+    mixed = bytearray(good)
+    for i in rng.integers(0, len(mixed), 300):
+        mixed[i] ^= 1 << int(rng.integers(0, 8))
+    out.append(bytes(mixed))
+    return out
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_batched_bytes_hostile_streams(mapping, lut, two_pass, monkeypatch):
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    if two_pass:
+        monkeypatch.setenv("SLAMHIP_FORCE_TWO_PASS", "1")
+    else:
+        monkeypatch.delenv("SLAMHIP_FORCE_TWO_PASS", raising=False)
+    streams = _hostile_streams()
+    offs, lens, blob = [], [], bytearray()
+    for sbytes in streams:
+        while len(blob) % 16:
+            blob.append(0xEE)
+        offs.append(len(blob)); lens.append(len(sbytes)); blob += sbytes
+    blob += b"\xEE" * 64
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
+    pipe.set_layout(offs, lens)
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    for f, sbytes in enumerate(streams):
+        by = np.frombuffer(sbytes, np.uint8)
+        rows_o, v, d = O.parse_groups(by)
+        assert (int(st[f, 2]), int(st[f, 3])) == (v, d), f
+        rows = pipe.frame_rows(f, st)
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k]), (f, k)
+        if v:
+            kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+            assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), f
+            kept = pipe.frame_kept(f, st)
+            for k in kept_o:
+                assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
