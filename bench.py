@@ -173,8 +173,7 @@ def main():
             "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
             "rows_summarize": 6.0 * valid,                   # ue, flag, rss
             "rows_groups": 6.0 * valid,
-            "rows_correct": 10.0 * valid + valid,            # flag, ue, rss, clk in; corrected-BS byte out
-            "rows_emit_kept": 10.0 * valid + 10.0 * kept,    # byte, ue, rss, clk in; kept rows out
+            "rows_finish": 10.0 * valid + 10.0 * kept,       # flag, ue, rss, clk in; kept rows out
             "pivot": 6.0 * kept,
             "raster": float(tile_bytes),
         }

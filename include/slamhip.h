@@ -146,13 +146,17 @@ typedef struct slam_batch {
      * [t*SLAM_TILE_BYTES, (t+1)*SLAM_TILE_BYTES) of frame f, in order, occupy entries
      * [t*SLAM_TILE_SLOTS, t*SLAM_TILE_SLOTS + tile_cnt_dev[f*T + t]) with T = slam_row_tiles(max_text_len,
      * src_is_bytes); the other entries of a tile are unused.  Concatenating the tiles' used entries gives
-     * the reference's record list.  Corrected rows (kept_*) are dense. */
+     * the reference's record list.  Corrected rows (kept_*) use the same scheme over blocks of
+     * SLAM_KEPT_BLOCK entries: the rows kept among entries [b*SLAM_KEPT_BLOCK, (b+1)*SLAM_KEPT_BLOCK) of the
+     * decoded arrays sit, in order, at the front of the same entries of the kept arrays, kept_cnt_dev[f*KB + b]
+     * of them, KB = ceil(row_cap / SLAM_KEPT_BLOCK). */
     uint32_t row_cap;             /* multiple of 16, >= T * SLAM_TILE_SLOTS                       */
     uint8_t *flag_dev, *ue_dev, *bs_dev;        /* decoded records                               */
     uint32_t *rss_dev, *clk_dev;
     uint32_t *tile_cnt_dev;       /* [F*T] records per tile (NULL: kept in the ctx workspace)     */
     uint8_t *kept_ue_dev, *kept_bs_dev;         /* corrected rows                                */
     uint32_t *kept_rss_dev, *kept_clk_dev;
+    uint32_t *kept_cnt_dev;       /* [F*KB] kept rows per block (NULL: kept in the ctx workspace) */
     uint32_t *stats_dev;          /* [F*SLAM_STAT_WORDS], see SLAM_STAT_*                         */
     double *matrix_dev;           /* [F*n_axis*n_axis] mean, NaN = empty (full axis grid)         */
     double *blurred_dev;          /* [F*n_axis*n_axis] blurred compact matrix, row stride n_aoa   */
@@ -161,6 +165,7 @@ typedef struct slam_batch {
 
 #define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
 #define SLAM_TILE_SLOTS     276   /* entries reserved per tile in the decoded-record arrays        */
+#define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays                 */
 /* Tiles per frame for frames of up to max_text_len text bytes (or data bytes when src_is_bytes). */
 uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 

@@ -651,6 +651,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
          (uintptr_t)bt->clk_dev) & 15u)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays must be 16-byte aligned");
+    const uint32_t kept_stride = (bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : cws.rt_nkept;
     if (stages & 1u) {
         SLAM_HIP(ctx, hipMemsetAsync(bt->stats_dev, 0, (size_t)F * SLAM_STAT_WORDS * 4, ctx->stream));
         frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev, nullptr, 0, nullptr};
@@ -660,7 +662,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if (stages & 2u) {
         rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap,
                                         tile_cnt, bp.st_max};
-        kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev};
+        kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev,
+                                          kept_cnt, kept_stride};
         if (bt->cycle <= 0 || bt->cycle > (1 << 30)) return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");
         correct_params prm;
         prm.set_cycle(bt->cycle);
@@ -675,7 +678,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
         int ks;
         SLAM_TRY(get_kernel(ctx, bt->blur_sigma, &kern, &ks));
         SLAM_TRY((pivot_accumulate<uint8_t, uint32_t>(ctx, bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev,
-                                                      bt->row_cap, F, bt->stats_dev, SLAM_STAT_KEPT, rp, rws)));
+                                                      bt->row_cap, F, bt->stats_dev, SLAM_STAT_ROW_SLOTS, rp, rws,
+                                                      kept_cnt, kept_stride)));
         SLAM_TRY(matrix_blur_render(ctx, F, rp, rws, kern, ks, bt->matrix_dev, bt->blurred_dev, bt->tile_dev,
                                     bt->stats_dev));
     }

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, ui
             else stats[f * SLAM_STAT_WORDS + stat_b] = cb;
         }
         if (grp_row) {
+            stats[f * SLAM_STAT_WORDS + SLAM_STAT_KEPT] = 0;       // accumulated by the fused correction kernel
             grp_row[(size_t)f * grp_stride + ca] = n;
             grp_bl[(size_t)f * grp_stride + ca] = nbl;
         }
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
     const size_t fb = (size_t)f * in.row_cap;
     uint32_t bound, base, live, prev;
     row_bits(in, fb, sp, i0, one_group, &bound, &base, &live, &prev);
+    if (ws.rmask && i0 < sp.n) ws.rmask[(fb + i0) >> 2] = (uint8_t)(bound | (live << 4));
     uint32_t tot;
     uint32_t packed = __popc(bound) | (__popc(base) << 16);       // both counts fit 16 bits per block
     uint32_t ex = block_excl_scan(packed, sh, &tot);
@@ -505,6 +507,107 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
     }
 }
 
+// Correction fused with the emission of kept rows (slotted layout of kept_out_t): group ids come from the
+// bits k_rows_groups left per 4 entries, a kept row goes straight to the front of its block's entries.
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint32_t rt_max, const uint32_t *rt_gbase,
+                                                      correct_ws ws, correct_params prm, kept_out_t<T8, T32> out,
+                                                      uint32_t *stats)
+{
+    __shared__ uint32_t sh[17];
+    __shared__ uint32_t t_rb[TAB_CAP];
+    __shared__ uint4 t_pay[TAB_CAP];
+    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
+    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
+    if (tile * ROWS_PER_BLOCK >= n) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    uint32_t bound = 0, live = 0;
+    T8 fl[4] = {1, 1, 1, 1}, ue[4] = {0, 0, 0, 0};
+    T32 ck[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+    if (i0 < n) {
+        const uint32_t mk = ws.rmask[(fb + i0) >> 2];
+        bound = mk & 15u;
+        live = mk >> 4;
+        load4(in.flag + fb + i0, fl);
+        load4(in.clk + fb + i0, ck);
+        load4(in.ue + fb + i0, ue);
+        load4(in.rss + fb + i0, rs);
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+    const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
+    const size_t gs = (size_t)f * (in.row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+    const uint32_t glo = gbase ? gbase - 1 : 0, ghi = gbase + tot - 1;
+    uint32_t gi[4], q1[4], r1[4];
+    int32_t res[4];
+    {
+        uint32_t g = gbase + ex;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((bound >> k) & 1u) g++;
+            gi[k] = g - 1;
+            res[k] = -1;
+            if (!((live >> k) & 1u)) fl[k] = 1;               // entries that are not rows take no part
+            phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
+        }
+    }
+    uint32_t keep = 0;
+    if ((ghi - glo) < TAB_MAX_GROUPS) {
+        for (uint32_t gg = glo; gg <= ghi; gg++) {
+            const uint32_t nd = ws.grp_nd[gs + gg];
+            if (nd == 0) continue;                              // block-uniform
+            const uint32_t *grb = ws.srt_rb + bsb + ws.grp_bl[gs + gg];
+            const uint4 *gpay = ws.srt_pay + bsb + ws.grp_bl[gs + gg];
+            const bool in_lds = nd <= TAB_CAP;
+            if (in_lds) {
+                for (uint32_t i = tid; i < nd; i += 256) { t_rb[i] = grb[i]; t_pay[i] = gpay[i]; }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (fl[k] == 1 || gi[k] != gg) continue;
+                int32_t bsn;
+                const bool hit = in_lds ? best_phase(t_rb, t_pay, nd, q1[k], r1[k], prm, &bsn)
+                                        : best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn);
+                if (hit) { res[k] = bsn; keep |= 1u << k; }
+            }
+            if (in_lds) __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (fl[k] == 1) continue;
+            const uint32_t nd = ws.grp_nd[gs + gi[k]];
+            if (nd == 0) continue;
+            int32_t bsn;
+            if (best_phase(ws.srt_rb + bsb + ws.grp_bl[gs + gi[k]], ws.srt_pay + bsb + ws.grp_bl[gs + gi[k]], nd,
+                           q1[k], r1[k], prm, &bsn)) {
+                res[k] = bsn;
+                keep |= 1u << k;
+            }
+        }
+    }
+    uint32_t nk;
+    const uint32_t kx = block_excl_scan(__popc(keep), sh, &nk);
+    size_t o = fb + (size_t)tile * ROWS_PER_BLOCK + kx;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((keep >> k) & 1u) {
+            out.ue[o] = ue[k];
+            out.bs[o] = (T8)res[k];
+            out.rss[o] = rs[k];
+            out.clk[o] = ck[k];
+            o++;
+        }
+    }
+    if (tid == 0) {
+        out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
+        if (nk) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, nk);
+    }
+}
+
 }  // namespace
 
 void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap, size_t off[16])
@@ -521,6 +624,7 @@ void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap,
     off[11] = p.add((size_t)F * row_cap * 4);
     off[12] = p.add((size_t)F * bl_cap * 4);
     off[13] = p.add((size_t)F * bl_cap * 4);
+    off[14] = p.add((size_t)F * row_cap / 4 + 16);
 }
 
 void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
@@ -539,6 +643,7 @@ void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
     corr = (int32_t *)(base + off[11]);
     tmp_a = (uint32_t *)(base + off[12]);
     tmp_b = (uint32_t *)(base + off[13]);
+    rmask = base + off[14];
     bl_cap = bl_cap_;
 }
 
@@ -579,6 +684,13 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), ws, in.row_cap, prm, stats);
+    if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
+        if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
+        if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
+        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), grid, block, in, rt_max, ws.rt_nbound, ws, prm, out,
+                    stats);
+        return SLAM_OK;
+    }
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
                 corr, prm, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,

@@ -29,7 +29,8 @@ struct v4<int32_t> { using type = int4; };
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
                                                 const uint32_t *stats, int stat_word, const int8_t *beam_to_axis,
-                                                int n_axis, unsigned long long *gsum, uint32_t *gcnt)
+                                                int n_axis, unsigned long long *gsum, uint32_t *gcnt,
+                                                const uint32_t *slot_cnt, uint32_t slot_stride)
 {
     __shared__ unsigned long long ssum[MAX_CELLS];
     __shared__ uint32_t scnt[MAX_CELLS];
@@ -53,9 +54,14 @@ __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const
         const int64_t uu[4] = {(int64_t)u.x, (int64_t)u.y, (int64_t)u.z, (int64_t)u.w};
         const int64_t bb[4] = {(int64_t)b.x, (int64_t)b.y, (int64_t)b.z, (int64_t)b.w};
         const int64_t rr[4] = {(int64_t)r.x, (int64_t)r.y, (int64_t)r.z, (int64_t)r.w};
+        uint32_t lim = r1;                     // slotted rows: only the front of each block of entries is used
+        if (slot_cnt) {
+            const uint32_t T = i0 / ROWS_PER_BLOCK;
+            lim = T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (i0 + k >= r1) break;
+            if (i0 + k >= lim) break;
             if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
             int c = b2a[uu[k]], rw = b2a[bb[k]];
             if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
@@ -365,7 +371,8 @@ void render_ws::bind(uint8_t *base, const size_t off[5])
 
 template <typename T8, typename T32>
 int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap, uint32_t F,
-                     const uint32_t *stats, int stat_word, const render_params &rp, const render_ws &ws)
+                     const uint32_t *stats, int stat_word, const render_params &rp, const render_ws &ws,
+                     const uint32_t *slot_cnt, uint32_t slot_stride)
 {
     if (F == 0) return SLAM_OK;
     if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
@@ -373,16 +380,16 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
     SLAM_HIP(ctx, hipMemsetAsync(ws.cnt, 0, (size_t)F * MAX_CELLS * 4, ctx->stream));
     dim3 grid((row_cap + PIVOT_CHUNK - 1) / PIVOT_CHUNK, F), block(256);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
-                rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt);
+                rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt, slot_cnt, slot_stride);
     return SLAM_OK;
 }
 
 template int pivot_accumulate<uint8_t, uint32_t>(slam_ctx *, const uint8_t *, const uint8_t *, const uint32_t *,
                                                  uint32_t, uint32_t, const uint32_t *, int, const render_params &,
-                                                 const render_ws &);
+                                                 const render_ws &, const uint32_t *, uint32_t);
 template int pivot_accumulate<int32_t, int32_t>(slam_ctx *, const int32_t *, const int32_t *, const int32_t *,
                                                 uint32_t, uint32_t, const uint32_t *, int, const render_params &,
-                                                const render_ws &);
+                                                const render_ws &, const uint32_t *, uint32_t);
 
 // Gaussian kernel of gaussian_kernel (:320-333), built on the host into `k` (size*size doubles); returns size.
 int slam_gaussian_kernel_host(double sigma, std::vector<double> &k)

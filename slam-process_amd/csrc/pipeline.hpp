@@ -64,7 +64,8 @@ uint32_t frame_tiles_for(int mode, uint32_t max_src_len);
 uint32_t slot_tiles_for(int mode, uint32_t max_src_len);
 
 // ---- correction ----------------------------------------------------------------------------------
-constexpr int ROWS_PER_BLOCK = 1024;             // 256 threads x 4 rows
+constexpr int ROWS_PER_BLOCK = SLAM_KEPT_BLOCK;  // 256 threads x 4 rows
+static_assert(ROWS_PER_BLOCK == 1024, "row kernels use 256 threads x 4 entries");
 
 template <typename T8, typename T32>
 struct rows_in_t {
@@ -75,10 +76,15 @@ struct rows_in_t {
     uint32_t slot_stride = 0;
 };
 
+// Kept (corrected) rows.  slot_cnt == nullptr: dense, in order.  Otherwise the kept rows among the entries
+// [T*ROWS_PER_BLOCK, (T+1)*ROWS_PER_BLOCK) of the input sit at the front of the same entries of the output,
+// slot_cnt[f*slot_stride + T] of them.
 template <typename T8, typename T32>
 struct kept_out_t {
     T8 *ue, *bs;
     T32 *rss, *clk;
+    uint32_t *slot_cnt = nullptr;
+    uint32_t slot_stride = 0;
 };
 
 struct correct_ws {
@@ -89,6 +95,7 @@ struct correct_ws {
     uint32_t *srt_rb;                            // [F * bl_cap] per group: distinct clk_b mod cycle, ascending
     uint4 *srt_pay;                              // same order: (baseline index in group, clk_b div cycle, bs_b, 0)
     int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
+    uint8_t *rmask;                              // [F * row_cap / 4] per 4 entries: group-start bits | row bits << 4
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
     static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }
@@ -131,10 +138,11 @@ struct render_ws {
     void bind(uint8_t *base, const size_t off[5]);
 };
 
+// slot_cnt != nullptr: the rows are slotted per ROWS_PER_BLOCK entries (kept_out_t) and stat_word counts entries
 template <typename T8, typename T32>
 int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
                      uint32_t F, const uint32_t *stats, int stat_word, const render_params &rp,
-                     const render_ws &ws);
+                     const render_ws &ws, const uint32_t *slot_cnt = nullptr, uint32_t slot_stride = 0);
 // sum/cnt -> mean matrix (full axis grid), compact + blur, scale, colours, index maps, tile.
 // kern is the ks x ks Gaussian kernel on the device (ks == 1: no blur).
 int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const render_ws &ws, const double *kern,

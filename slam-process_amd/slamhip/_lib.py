@@ -20,7 +20,7 @@ STAT_WORDS = 16
 (STAT_NBYTES, STAT_NOT_STRICT, STAT_VALID, STAT_DISCARDED, STAT_GROUPS, STAT_BASELINES, STAT_KEPT,
  STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI,
  STAT_ROW_SLOTS, STAT_TWO_PASS) = range(16)
-TILE_BYTES, TILE_SLOTS = 3024, 276
+TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_sync", "slam_last_error", "slam_version",
@@ -51,7 +51,7 @@ class Batch(C.Structure):
         ("flag_dev", C.c_void_p), ("ue_dev", C.c_void_p), ("bs_dev", C.c_void_p),
         ("rss_dev", C.c_void_p), ("clk_dev", C.c_void_p), ("tile_cnt_dev", C.c_void_p),
         ("kept_ue_dev", C.c_void_p), ("kept_bs_dev", C.c_void_p),
-        ("kept_rss_dev", C.c_void_p), ("kept_clk_dev", C.c_void_p),
+        ("kept_rss_dev", C.c_void_p), ("kept_clk_dev", C.c_void_p), ("kept_cnt_dev", C.c_void_p),
         ("stats_dev", C.c_void_p), ("matrix_dev", C.c_void_p), ("blurred_dev", C.c_void_p),
         ("tile_dev", C.c_void_p),
     ]

@@ -65,6 +65,8 @@ class FramePipeline:
         self.rss = torch.empty(F * rc, dtype=u32, device=d)
         self.clk = torch.empty(F * rc, dtype=u32, device=d)
         self.tile_cnt = torch.zeros(F * self.row_tiles, dtype=u32, device=d)
+        self.kept_blocks = (rc + _lib.KEPT_BLOCK - 1) // _lib.KEPT_BLOCK
+        self.kept_cnt = torch.zeros(F * self.kept_blocks, dtype=u32, device=d)
         self.k_ue = torch.empty(F * rc, dtype=u8, device=d)
         self.k_bs = torch.empty(F * rc, dtype=u8, device=d)
         self.k_rss = torch.empty(F * rc, dtype=u32, device=d)
@@ -97,6 +99,7 @@ class FramePipeline:
         bt.tile_cnt_dev = self.tile_cnt.data_ptr()
         bt.kept_ue_dev, bt.kept_bs_dev = self.k_ue.data_ptr(), self.k_bs.data_ptr()
         bt.kept_rss_dev, bt.kept_clk_dev = self.k_rss.data_ptr(), self.k_clk.data_ptr()
+        bt.kept_cnt_dev = self.kept_cnt.data_ptr()
         bt.stats_dev = self.stats.data_ptr()
         bt.matrix_dev = self.matrix.data_ptr()
         bt.blurred_dev = self.blurred.data_ptr()
@@ -154,11 +157,20 @@ class FramePipeline:
         return out
 
     def frame_kept(self, f: int, st: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+        """Corrected rows of frame f in order (the used entries of its blocks, concatenated)."""
         st = self.stats_host() if st is None else st
-        n, rc = int(st[f, _lib.STAT_KEPT]), self.row_cap
-        sl = slice(f * rc, f * rc + n)
-        return dict(ue=self.k_ue[sl].cpu().numpy(), bs=self.k_bs[sl].cpu().numpy(),
-                    rss=self.k_rss[sl].cpu().numpy().view(np.uint32), clk=self.k_clk[sl].cpu().numpy().view(np.uint32))
+        rc, KB, S = self.row_cap, self.kept_blocks, _lib.KEPT_BLOCK
+        span = int(st[f, _lib.STAT_ROW_SLOTS])
+        nb = (span + S - 1) // S
+        cnt = self.kept_cnt[f * KB:f * KB + nb].to(torch.int64)
+        use = (torch.arange(S, device=self.dev)[None, :] < cnt[:, None]).reshape(-1)[:min(nb * S, rc)]
+        sl = slice(f * rc, f * rc + len(use))
+        out = dict(ue=self.k_ue[sl][use].cpu().numpy(), bs=self.k_bs[sl][use].cpu().numpy(),
+                   rss=self.k_rss[sl][use].cpu().numpy().view(np.uint32),
+                   clk=self.k_clk[sl][use].cpu().numpy().view(np.uint32))
+        if len(out["ue"]) != int(st[f, _lib.STAT_KEPT]):
+            raise RuntimeError("block counts and the frame's kept count disagree")
+        return out
 
     def frame_matrix(self, f: int, st: Optional[np.ndarray] = None):
         """(full-grid mean [n_axis,n_axis], compact blurred [n_aod,n_aoa], aod angles, aoa angles, vmin, vmax)."""
