@@ -121,14 +121,17 @@ __device__ __forceinline__ void row_bits(const rows_in_t<T8, T32> &in, size_t fb
 
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
-                                                         uint32_t *rt_nbound, uint32_t *rt_nbase,
+                                                         uint32_t *rt_nbound, uint32_t *rt_nbase, uint16_t *rmask,
                                                          const uint32_t *stats)
 {
     __shared__ uint32_t sh[8];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const frame_span sp = span_of(in, f, stats);
     uint32_t bound, base, live, prev;
-    row_bits(in, (size_t)f * in.row_cap, sp, tile * ROWS_PER_BLOCK + tid * 4, one_group, &bound, &base, &live, &prev);
+    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
+    row_bits(in, (size_t)f * in.row_cap, sp, i0, one_group, &bound, &base, &live, &prev);
+    // the later row kernels take these bits instead of reading the columns again
+    if (i0 < sp.n) rmask[((size_t)f * in.row_cap + i0) >> 2] = (uint16_t)(bound | (base << 4) | (live << 8));
     uint32_t cb = wave_sum(__popc(bound)), cl = wave_sum(__popc(base));
     if (lane_id() == 0) { sh[tid >> 6] = cb; sh[4 + (tid >> 6)] = cl; }
     __syncthreads();
@@ -190,9 +193,14 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
     if (tile * ROWS_PER_BLOCK >= sp.n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    uint32_t bound, base, live, prev;
-    row_bits(in, fb, sp, i0, one_group, &bound, &base, &live, &prev);
-    if (ws.rmask && i0 < sp.n) ws.rmask[(fb + i0) >> 2] = (uint8_t)(bound | (live << 4));
+    uint32_t bound = 0, base = 0, live = 0, prev = NO_ROW;
+    if (i0 < sp.n) {
+        const uint32_t mk = ws.rmask[(fb + i0) >> 2];
+        bound = mk & 15u;
+        base = (mk >> 4) & 15u;
+        live = mk >> 8;
+        if (base & 1u) live4(sp, i0, &prev);          // a baseline's clock is that of the row before it
+    }
     uint32_t tot;
     uint32_t packed = __popc(bound) | (__popc(base) << 16);       // both counts fit 16 bits per block
     uint32_t ex = block_excl_scan(packed, sh, &tot);
@@ -393,8 +401,12 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
     if (tile * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    uint32_t bound, base, live, prev;
-    row_bits(in, fb, sp, i0, one_group, &bound, &base, &live, &prev);
+    uint32_t bound = 0, live = 0;
+    if (i0 < n) {
+        const uint32_t mk = ws.rmask[(fb + i0) >> 2];
+        bound = mk & 15u;
+        live = mk >> 8;
+    }
     uint32_t tot;
     const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
     const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
@@ -517,6 +529,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     __shared__ uint32_t sh[17];
     __shared__ uint32_t t_rb[TAB_CAP];
     __shared__ uint4 t_pay[TAB_CAP];
+    __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
     const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
@@ -528,18 +541,27 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     if (i0 < n) {
         const uint32_t mk = ws.rmask[(fb + i0) >> 2];
         bound = mk & 15u;
-        live = mk >> 4;
+        live = mk >> 8;
         load4(in.flag + fb + i0, fl);
         load4(in.clk + fb + i0, ck);
         load4(in.ue + fb + i0, ue);
         load4(in.rss + fb + i0, rs);
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+    // groups this block touches: the one running into it and those starting in it.  Their table descriptors
+    // are fetched while the row loads are in flight (the next block's base gives the count without a scan).
     const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
+    const uint32_t gnext = (tile + 1) * ROWS_PER_BLOCK < n ? rt_gbase[(size_t)f * rt_max + tile + 1]
+                                                           : stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
     const size_t gs = (size_t)f * (in.row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
-    const uint32_t glo = gbase ? gbase - 1 : 0, ghi = gbase + tot - 1;
+    const uint32_t glo = gbase ? gbase - 1 : 0, ghi = gnext - 1;
+    const bool staged = (ghi - glo) < TAB_MAX_GROUPS;
+    if (staged && tid <= ghi - glo) {
+        g_nd[tid] = ws.grp_nd[gs + glo + tid];
+        g_bl[tid] = ws.grp_bl[gs + glo + tid];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);      // also publishes g_nd / g_bl
     uint32_t gi[4], q1[4], r1[4];
     int32_t res[4];
     {
@@ -554,12 +576,12 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         }
     }
     uint32_t keep = 0;
-    if ((ghi - glo) < TAB_MAX_GROUPS) {
+    if (staged) {
         for (uint32_t gg = glo; gg <= ghi; gg++) {
-            const uint32_t nd = ws.grp_nd[gs + gg];
+            const uint32_t nd = g_nd[gg - glo];
             if (nd == 0) continue;                              // block-uniform
-            const uint32_t *grb = ws.srt_rb + bsb + ws.grp_bl[gs + gg];
-            const uint4 *gpay = ws.srt_pay + bsb + ws.grp_bl[gs + gg];
+            const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo];
+            const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo];
             const bool in_lds = nd <= TAB_CAP;
             if (in_lds) {
                 for (uint32_t i = tid; i < nd; i += 256) { t_rb[i] = grb[i]; t_pay[i] = gpay[i]; }
@@ -624,7 +646,7 @@ void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap,
     off[11] = p.add((size_t)F * row_cap * 4);
     off[12] = p.add((size_t)F * bl_cap * 4);
     off[13] = p.add((size_t)F * bl_cap * 4);
-    off[14] = p.add((size_t)F * row_cap / 4 + 16);
+    off[14] = p.add((size_t)F * row_cap / 2 + 16);
 }
 
 void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
@@ -643,7 +665,7 @@ void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
     corr = (int32_t *)(base + off[11]);
     tmp_a = (uint32_t *)(base + off[12]);
     tmp_b = (uint32_t *)(base + off[13]);
-    rmask = base + off[14];
+    rmask = (uint16_t *)(base + off[14]);
     bl_cap = bl_cap_;
 }
 
@@ -678,7 +700,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     const int og = (prm.one_group || prm.explicit_baselines ? 1 : 0) | (prm.explicit_baselines ? 2 : 0);
     const int keep_bl = prm.explicit_baselines ? 1 : 0;
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
-                ws.rt_nbase, stats);
+                ws.rt_nbase, ws.rmask, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
                 (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,

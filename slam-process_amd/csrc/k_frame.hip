@@ -107,14 +107,15 @@ __device__ __forceinline__ uint32_t nib4(uint32_t w)
     return (w & 0x0F0F0F0Fu) + a + (a << 3);
 }
 
-// 0x80 in every byte of w that is not an ASCII hex digit
+// Bit 7 of every byte of the result is set when that byte of w is not an ASCII hex digit, provided no byte
+// of w has its own bit 7 set (a byte >= 0x80 can carry into its neighbour's test; callers also accumulate w
+// itself, whose bit 7 then marks the word as bad anyway).  The other bits of the result are noise.
 __device__ __forceinline__ uint32_t not_hex4(uint32_t w)
 {
-    uint32_t t = w ^ 0x30303030u;
-    uint32_t dbad = (t + 0x76767676u) & 0x80808080u;
-    uint32_t u = (w | 0x20202020u) ^ 0x60606060u;
-    uint32_t abad = ((u + 0x79797979u) | ~(u + 0x7F7F7F7Fu)) & 0x80808080u;
-    return (dbad & abad) | (w & 0x80808080u);
+    const uint32_t a = (w ^ 0x30303030u) + 0x76767676u;              // bit 7 set: not '0'..'9'
+    const uint32_t u = (w | 0x20202020u) ^ 0x60606060u;              // letters a-f / A-F -> 1..6
+    const uint32_t b = u + 0x79797979u, c = u + 0x7F7F7F7Fu;         // bit 7 of b: u > 6;  bit 7 clear in c: u == 0
+    return a & (b | ~c);
 }
 
 __device__ __forceinline__ int hexval(uint32_t c)
@@ -128,6 +129,10 @@ __device__ __forceinline__ int hexval(uint32_t c)
 // 12 text bytes "HL HL HL HL " (t0 = bytes 0..3, t1 = 4..7, t2 = 8..11) -> 4 data bytes.
 // v_perm gathers the four high-nibble characters, the four low-nibble characters and the four
 // separators into one dword each; nibble values and the format check are then 4-wide SWAR.
+// *bad collects two things: bit 7 of any byte set = a character is not a hex digit (or not ASCII);
+// any bit of the low 7 of any byte set through the separator term = a separator is not a space.  The
+// separator term is shifted out of the way of the bit-7 noise of not_hex4, so callers test (*bad & BAD_MASK).
+constexpr uint32_t BAD_MASK = 0x80808080u;
 template <bool VALIDATE>
 __device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t *bad)
 {
@@ -138,7 +143,10 @@ __device__ __forceinline__ uint32_t decode12(uint32_t t0, uint32_t t1, uint32_t 
     if (VALIDATE) {
         const uint32_t sa = __builtin_amdgcn_perm(t1, t0, 0x0C0C0502u);
         const uint32_t sp = __builtin_amdgcn_perm(t2, sa, 0x07040100u);
-        *bad |= not_hex4(h) | not_hex4(l) | (sp ^ 0x20202020u);      // non-zero: not the strict capture format
+        // separators: x = sp ^ "    " is zero when right; x + 0x7F.. sets bit 7 of every non-zero byte below 0x81,
+        // and a byte >= 0x80 shows in x itself
+        const uint32_t x = sp ^ 0x20202020u;
+        *bad |= not_hex4(h) | not_hex4(l) | h | l | x | (x + 0x7F7F7F7Fu);
     }
     return (nib4(h) << 4) | nib4(l);
 }
@@ -166,8 +174,8 @@ __device__ __forceinline__ uint32_t load_data_dword(const src_view &sv, uint32_t
             uint32_t o = 3u * b;
             int h = hexval(sv.p[o]);
             int l = (o + 1 < sv.n_src) ? hexval(sv.p[o + 1]) : -1;
-            if (h < 0 || l < 0) { *bad |= 1u; h = 0; l = 0; }
-            if (o + 2 < sv.n_src && sv.p[o + 2] != 0x20) *bad |= 1u;
+            if (h < 0 || l < 0) { *bad |= BAD_MASK; h = 0; l = 0; }
+            if (o + 2 < sv.n_src && sv.p[o + 2] != 0x20) *bad |= BAD_MASK;
             val |= (uint32_t)((h << 4) | l) << (8 * k);
         }
         return val;
@@ -249,17 +257,20 @@ struct run_masks {
     uint64_t endbit;  // where a visited tail position sends the orbit (first position past the data)
 };
 
-// bits 0, 8, 16, 24 of x01 -> bits 0..3
-__device__ __forceinline__ uint32_t movemask4(uint32_t x01)
+// One bit per byte of a dword pair -> 8 mask bits.  v_dot4_u32_u8 sums byte products, so with the wanted bit
+// isolated (byte value 2^k or 0) and weights 1,2,4,8 / 16,32,64,128 two dot products leave the eight bits of
+// dwords (a, b) at bit positions k .. k+7 of the result.
+__device__ __forceinline__ uint32_t pair_bits(uint32_t a, uint32_t b, uint32_t bitmask)
 {
-    uint32_t t = x01 | (x01 >> 7);
-    return (t | (t >> 14)) & 0xFu;
+    return __builtin_amdgcn_udot4(b & bitmask, 0x80402010u, __builtin_amdgcn_udot4(a & bitmask, 0x08040201u, 0u, false), false);
 }
 
-__device__ __forceinline__ uint32_t zero_bytes4(uint32_t v)   // 0x80 in every zero byte, exact
+// bit 7 of every byte that is NOT a flag byte (0x33 / 0xCC): x ^ 0x33 is then 0x00 or 0xFF, i.e. all eight bits
+// equal, i.e. the low seven bits of v ^ (v >> 1) are zero
+__device__ __forceinline__ uint32_t not_flag4(uint32_t x)
 {
-    uint32_t y = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(y | v | 0x7F7F7F7Fu);
+    const uint32_t u = (x ^ (x >> 1) ^ 0x2AAAAAAAu) & 0x7F7F7F7Fu;     // 0x2AAAAAAA = 0x33333333 ^ (0x33333333 >> 1)
+    return u + 0x7F7F7F7Fu;
 }
 
 // `tile` is the wave's LDS tile; `rem` = data bytes from the run's first position to the end (<= 0: none).
@@ -272,19 +283,23 @@ __device__ __forceinline__ run_masks make_masks(const uint32_t *tile, int64_t re
         uint4 q = t4[i];
         w[4 * i + 0] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
     }
-    uint64_t b7 = 0, b6 = 0, fl = 0;
+    uint32_t p7[8], p6[8], pn[6];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        uint32_t x = w[i];
-        b7 |= (uint64_t)movemask4((x >> 7) & 0x01010101u) << (4 * i);
-        b6 |= (uint64_t)movemask4((x >> 6) & 0x01010101u) << (4 * i);
-        // flag bytes: 0xCC ^ 0xCC = 0x00 and 0x33 ^ 0xCC = 0xFF; spread each byte's top bit over the
-        // byte and xor it away: both become 0x00, nothing else does
-        uint32_t y = x ^ 0xCCCCCCCCu;
-        uint32_t top = (y >> 7) & 0x01010101u;
-        uint32_t spread = (top << 8) - top;
-        fl |= (uint64_t)movemask4(zero_bytes4(y ^ spread) >> 7) << (4 * i);
+    for (int j = 0; j < 8; j++) {
+        p7[j] = pair_bits(w[2 * j], w[2 * j + 1], 0x80808080u);        // 8 bits at 7..14
+        p6[j] = pair_bits(w[2 * j], w[2 * j + 1], 0x40404040u);        // 8 bits at 6..13
     }
+#pragma unroll
+    for (int j = 0; j < 6; j++)                                        // flags matter at the run's own 48 positions
+        pn[j] = pair_bits(not_flag4(w[2 * j]), not_flag4(w[2 * j + 1]), 0x80808080u);
+    const uint32_t b7l = (p7[0] >> 7) | (p7[1] << 1) | (p7[2] << 9) | (p7[3] << 17);
+    const uint32_t b7h = (p7[4] >> 7) | (p7[5] << 1) | (p7[6] << 9) | (p7[7] << 17);
+    const uint32_t b6l = (p6[0] >> 6) | (p6[1] << 2) | (p6[2] << 10) | (p6[3] << 18);
+    const uint32_t b6h = (p6[4] >> 6) | (p6[5] << 2) | (p6[6] << 10) | (p6[7] << 18);
+    const uint32_t nfl = (pn[0] >> 7) | (pn[1] << 1) | (pn[2] << 9) | (pn[3] << 17);
+    const uint32_t nfh = (pn[4] >> 7) | (pn[5] << 1);
+    const uint64_t b7 = ((uint64_t)b7h << 32) | b7l, b6 = ((uint64_t)b6h << 32) | b6l;
+    const uint64_t fl = ~(((uint64_t)nfh << 32) | nfl) & ((1ull << FRAME_RUN) - 1);
     const uint64_t own = (1ull << FRAME_RUN) - 1;
     uint64_t m0 = ~b7 & ~b6, m1 = ~b7 & b6, m2 = b7 & ~b6, m3 = b7 & b6;
     uint64_t c2 = m1 & (m1 >> 1);
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
     }
     wave_lds_sync();
     }
-    if (bad) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
+    if (bad & BAD_MASK) stats[f * SLAM_STAT_WORDS + SLAM_STAT_NOT_STRICT] = 1;
 }
 
 // ---- per-frame scan over tiles --------------------------------------------------------------------
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
         if (accv) atomicAdd(st + SLAM_STAT_VALID, accv);
         if (accd) atomicAdd(st + SLAM_STAT_DISCARDED, accd);
     }
-    if (bad) st[SLAM_STAT_NOT_STRICT] = 1;
+    if (bad & BAD_MASK) st[SLAM_STAT_NOT_STRICT] = 1;
     if (unsync) st[SLAM_STAT_TWO_PASS] = 1;
 }
 

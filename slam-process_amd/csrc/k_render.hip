@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int PIVOT_CHUNK = 16384;     // rows per workgroup of the pivot
+constexpr int PIVOT_CHUNK = 65536;     // rows per workgroup of the pivot
 constexpr int MAX_AXIS = 64;
 constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
 
@@ -48,17 +48,18 @@ __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const
     for (uint32_t i0 = r0 + tid * 4; i0 < r1; i0 += 1024) {
         using V8 = typename v4<T8>::type;
         using V32 = typename v4<T32>::type;
+        uint32_t lim = r1;                     // slotted rows: only the front of each block of entries is used
+        if (slot_cnt) {
+            const uint32_t T = i0 / ROWS_PER_BLOCK;
+            lim = T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T];
+            if (i0 >= lim) continue;
+        }
         V8 u = *reinterpret_cast<const V8 *>(ue + fb + i0);
         V8 b = *reinterpret_cast<const V8 *>(bs + fb + i0);
         V32 r = *reinterpret_cast<const V32 *>(rss + fb + i0);
         const int64_t uu[4] = {(int64_t)u.x, (int64_t)u.y, (int64_t)u.z, (int64_t)u.w};
         const int64_t bb[4] = {(int64_t)b.x, (int64_t)b.y, (int64_t)b.z, (int64_t)b.w};
         const int64_t rr[4] = {(int64_t)r.x, (int64_t)r.y, (int64_t)r.z, (int64_t)r.w};
-        uint32_t lim = r1;                     // slotted rows: only the front of each block of entries is used
-        if (slot_cnt) {
-            const uint32_t T = i0 / ROWS_PER_BLOCK;
-            lim = T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T];
-        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (i0 + k >= lim) break;

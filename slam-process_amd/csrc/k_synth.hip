@@ -119,11 +119,47 @@ __global__ __launch_bounds__(256) void k_read_tiles(uint32_t *dst, const uint8_t
     if (lane == 0 && acc == 0x12345u) dst[0] = acc;
 }
 
+// copy-like probes: read n16 16-byte words, write every RATIO-th of them; NT: 0 plain, 1 non-temporal stores,
+// 2 non-temporal loads and stores
+template <int RATIO, int NT>
+__global__ __launch_bounds__(256) void k_mix16(uint4 *dst, const uint4 *src, size_t n16)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u *s = reinterpret_cast<const v4u *>(src);
+    v4u *d = reinterpret_cast<v4u *>(dst);
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * RATIO; i + RATIO <= n16; i += (size_t)gridDim.x * 256 * RATIO) {
+        v4u acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < RATIO; r++) {
+            v4u v = NT == 2 ? __builtin_nontemporal_load(s + i + r) : s[i + r];
+            acc ^= v;
+        }
+        if (NT) __builtin_nontemporal_store(acc, d + i / RATIO);
+        else d[i / RATIO] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int slam_read_probe_dev(slam_ctx *ctx, void *scratch_dev, const void *src_dev, size_t n, int mode)
 {
     if (!ctx || !scratch_dev || !src_dev) return SLAM_E_INVALID;
+    if (mode >= 10) {         // scratch_dev is a destination of n bytes (modes 10-12) or n/3 bytes (20-22)
+        dim3 g(4096), b(256);
+        uint4 *d = (uint4 *)scratch_dev;
+        const uint4 *sp = (const uint4 *)src_dev;
+        const size_t n16 = n / 16;
+        switch (mode) {
+        case 10: SLAM_LAUNCH(ctx, "mix1_0", (k_mix16<1, 0>), g, b, d, sp, n16); break;
+        case 11: SLAM_LAUNCH(ctx, "mix1_1", (k_mix16<1, 1>), g, b, d, sp, n16); break;
+        case 12: SLAM_LAUNCH(ctx, "mix1_2", (k_mix16<1, 2>), g, b, d, sp, n16); break;
+        case 20: SLAM_LAUNCH(ctx, "mix3_0", (k_mix16<3, 0>), g, b, d, sp, n16); break;
+        case 21: SLAM_LAUNCH(ctx, "mix3_1", (k_mix16<3, 1>), g, b, d, sp, n16); break;
+        case 22: SLAM_LAUNCH(ctx, "mix3_2", (k_mix16<3, 2>), g, b, d, sp, n16); break;
+        default: return slam_fail(ctx, SLAM_E_INVALID, "unknown probe mode");
+        }
+        return SLAM_OK;
+    }
     const size_t per = mode == 3 ? 12288 : 9216;
     const size_t nt = (n - 64) / per;
     dim3 grid((uint32_t)((nt + 3) / 4)), block(256);

@@ -95,7 +95,7 @@ struct correct_ws {
     uint32_t *srt_rb;                            // [F * bl_cap] per group: distinct clk_b mod cycle, ascending
     uint4 *srt_pay;                              // same order: (baseline index in group, clk_b div cycle, bs_b, 0)
     int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
-    uint8_t *rmask;                              // [F * row_cap / 4] per 4 entries: group-start bits | row bits << 4
+    uint16_t *rmask;                             // [F * row_cap / 4] per 4 entries: group-start bits | baseline bits << 4 | row bits << 8
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
     static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }

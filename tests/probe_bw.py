@@ -32,3 +32,15 @@ for mode in (1, 2, 3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print(f"tile-shaped read mode {mode}: {n / dt / 1e12:.2f} TB/s")
+
+for mode, traffic in ((10, 2 * n), (11, 2 * n), (12, 2 * n), (20, n + n // 3), (21, n + n // 3), (22, n + n // 3)):
+    for _ in range(3):
+        c.check(lib.slam_read_probe_dev(c.h, C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, mode))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        c.check(lib.slam_read_probe_dev(c.h, C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, mode))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print(f"read:write {'1:1' if mode < 20 else '3:1'} mode {mode % 10} (0 plain, 1 nt stores, 2 nt loads+stores): "
+          f"{traffic / dt / 1e12:.2f} TB/s total")
