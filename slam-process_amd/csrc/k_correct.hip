@@ -349,16 +349,12 @@ struct corr_none<int32_t> { static constexpr int32_t v = -1; };
 constexpr int TAB_CAP = 1024;         // phases of one group staged in LDS by k_rows_correct
 constexpr uint32_t TAB_MAX_GROUPS = 16; // tiles spanning more groups than this search the tables in global memory
 
-// Nearest phase of (q1, r) in a group's table rb[0..nd) / pay[0..nd): returns true and the corrected BS.
+// Given lo = number of table phases below r: pick between the circular neighbours, apply the tolerance
+// and round.  Returns true and the corrected BS when a baseline qualifies.
 template <typename RB, typename PAY>
-__device__ __forceinline__ bool best_phase(const RB *rb, const PAY *pay, uint32_t nd, uint32_t q1, uint32_t r,
-                                           const correct_params &prm, int32_t *out_bs)
+__device__ __forceinline__ bool decide_phase(const RB *rb, const PAY *pay, uint32_t nd, uint32_t lo, uint32_t q1,
+                                             uint32_t r, const correct_params &prm, int32_t *out_bs)
 {
-    uint32_t lo = 0, hi = nd;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (rb[mid] < r) lo = mid + 1; else hi = mid;
-    }
     const uint32_t is = lo < nd ? lo : 0, ip = lo > 0 ? lo - 1 : nd - 1;      // circular successor / predecessor
     const uint32_t vs = rb[is], vp = rb[ip];
     const uint32_t cyc = (uint32_t)prm.cycle;
@@ -382,6 +378,19 @@ __device__ __forceinline__ bool best_phase(const RB *rb, const PAY *pay, uint32_
     const int32_t v = (int32_t)ws_.z + k;
     *out_bs = (prm.mod_base & (prm.mod_base - 1)) == 0 ? (v & (prm.mod_base - 1)) : pymod(v, prm.mod_base);
     return true;
+}
+
+// Nearest phase of (q1, r) in a group's table rb[0..nd) / pay[0..nd): returns true and the corrected BS.
+template <typename RB, typename PAY>
+__device__ __forceinline__ bool best_phase(const RB *rb, const PAY *pay, uint32_t nd, uint32_t q1, uint32_t r,
+                                           const correct_params &prm, int32_t *out_bs)
+{
+    uint32_t lo = 0, hi = nd;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rb[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    return decide_phase(rb, pay, nd, lo, q1, r, prm, out_bs);
 }
 
 // Per row: nearest baseline phase of its group -> corrected BS or "none"; kept count per tile.
@@ -519,8 +528,10 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
     }
 }
 
-// Correction fused with the emission of kept rows (slotted layout of kept_out_t): group ids come from the
-// bits k_rows_groups left per 4 entries, a kept row goes straight to the front of its block's entries.
+// Correction fused with the emission of kept rows (slotted layout of kept_out_t):
+// group ids come from the bits k_rows_summarize left per 4 entries, the four rows of a thread search their
+// group's LDS-staged phase table in lock step (fixed trip count over the table padded to a power of two), and a
+// kept row goes straight to the front of its block's entries.
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint32_t rt_max, const uint32_t *rt_gbase,
                                                       correct_ws ws, correct_params prm, kept_out_t<T8, T32> out,
@@ -582,20 +593,34 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
             if (nd == 0) continue;                              // block-uniform
             const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo];
             const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo];
-            const bool in_lds = nd <= TAB_CAP;
-            if (in_lds) {
-                for (uint32_t i = tid; i < nd; i += 256) { t_rb[i] = grb[i]; t_pay[i] = gpay[i]; }
+            if (nd < TAB_CAP) {
+                uint32_t P = 2;                                 // power of two > nd: the padded table length
+                while (P <= nd) P <<= 1;
+                for (uint32_t i = tid; i < P; i += 256) {
+                    t_rb[i] = i < nd ? grb[i] : 0xFFFFFFFFu;
+                    if (i < nd) t_pay[i] = gpay[i];
+                }
                 __syncthreads();
-            }
+                uint32_t lo[4] = {0, 0, 0, 0};
+                for (uint32_t h = P >> 1; h; h >>= 1) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (fl[k] == 1 || gi[k] != gg) continue;
-                int32_t bsn;
-                const bool hit = in_lds ? best_phase(t_rb, t_pay, nd, q1[k], r1[k], prm, &bsn)
-                                        : best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn);
-                if (hit) { res[k] = bsn; keep |= 1u << k; }
+                    for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (fl[k] == 1 || gi[k] != gg) continue;
+                    int32_t bsn;
+                    if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (fl[k] == 1 || gi[k] != gg) continue;
+                    int32_t bsn;
+                    if (best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                }
             }
-            if (in_lds) __syncthreads();
         }
     } else {
 #pragma unroll

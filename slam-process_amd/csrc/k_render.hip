@@ -32,16 +32,18 @@ __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const
                                                 int n_axis, unsigned long long *gsum, uint32_t *gcnt,
                                                 const uint32_t *slot_cnt, uint32_t slot_stride)
 {
-    __shared__ unsigned long long ssum[MAX_CELLS];
-    __shared__ uint32_t scnt[MAX_CELLS];
+    // One packed accumulator per cell: count in the top 17 bits, sum below (a chunk holds 2^16 rows of less
+    // than 2^31 each, so the sum stays under 2^47).  Rows are padded to 65 cells: consecutive BS beams at one
+    // UE beam are n_axis cells apart, which would put a whole wave on one LDS bank.
+    constexpr int LSTRIDE = MAX_AXIS + 1;
+    __shared__ unsigned long long acc[MAX_AXIS * LSTRIDE];
     __shared__ int8_t b2a[64];
     const uint32_t f = blockIdx.y, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + stat_word];
     const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
     if (r0 >= n) return;
     const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
-    const int cells = n_axis * n_axis;
-    for (int i = tid; i < cells; i += 256) { ssum[i] = 0; scnt[i] = 0; }
+    for (int i = tid; i < n_axis * LSTRIDE; i += 256) acc[i] = 0;
     if (tid < 64) b2a[tid] = beam_to_axis[tid];
     __syncthreads();
     const size_t fb = (size_t)f * row_cap;
@@ -66,17 +68,15 @@ __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const
             if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
             int c = b2a[uu[k]], rw = b2a[bb[k]];
             if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
-            int cell = rw * n_axis + c;
-            atomicAdd(&ssum[cell], (unsigned long long)rr[k]);
-            atomicAdd(&scnt[cell], 1u);
+            atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << 47));
         }
     }
     __syncthreads();
-    for (int i = tid; i < cells; i += 256) {
-        uint32_t c = scnt[i];
-        if (c) {
-            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], ssum[i]);
-            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], c);
+    for (int i = tid; i < n_axis * n_axis; i += 256) {
+        const unsigned long long a = acc[(i / n_axis) * LSTRIDE + (i % n_axis)];
+        if (a >> 47) {
+            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], a & ((1ull << 47) - 1));
+            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], (uint32_t)(a >> 47));
         }
     }
 }
