@@ -181,22 +181,23 @@ def main():
         for name, (launches, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1]):
             per = ms / max(launches, 1)
             ent = dict(launches=launches, avg_ms=round(per, 5), share=round(ms / tot_ms, 4))
-            if name in alg:
-                ent["alg_GBps"] = round(alg[name] * F / (per * 1e-3) / 1e9, 1)
+            if name in alg:        # frames one launch covers: the library may cut a step into sub-batches
+                ent["alg_GBps"] = round(alg[name] * (F * K / max(launches, 1)) / (per * 1e-3) / 1e9, 1)
             kern_table[name] = ent
         dom = max((n for n in kern if n in alg), key=lambda n: kern[n][1])
         per = kern[dom][1] / kern[dom][0]
-        ach = alg[dom] * F / (per * 1e-3) / 1e9
+        fpl = F * K / kern[dom][0]                     # frames per launch of the dominant kernel
+        ach = alg[dom] * fpl / (per * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 PMC passes (same shape)
             pj = json.load(open(pmc))
             if pj.get("shape") == [B, N] and dom in pj["kernels"]:
                 kk = pj["kernels"][dom]
-                traffic = int((kk["fetch_bytes_per_frame"] + kk["write_bytes_per_frame"]) * F)
+                traffic = int((kk["fetch_bytes_per_frame"] + kk["write_bytes_per_frame"]) * fpl)
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                    alg_bytes_per_launch=int(alg[dom] * F), avg_launch_ms=round(per, 5))
+                    alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
 
     out = {
         "metric": "frames/s (256-beam x 4096-sample decode+correct+raster)",

@@ -349,6 +349,24 @@ struct corr_none<int32_t> { static constexpr int32_t v = -1; };
 constexpr int TAB_CAP = 1024;         // phases of one group staged in LDS by k_rows_correct
 constexpr uint32_t TAB_MAX_GROUPS = 16; // tiles spanning more groups than this search the tables in global memory
 
+// Corrected BS for a row (clk div cycle = q1, clk mod cycle = r) against the chosen baseline (clk_b div cycle = qb,
+// clk_b mod cycle = vw, beam bs_b): d = clk - clk_b = Q*cycle + x with |x| < cycle, k = round-half-even(d / cycle),
+// result (bs_b + k) mod MOD_BASE (bs_beam_correction.py:103-112).
+__device__ __forceinline__ int32_t round_to_beam(uint32_t q1, uint32_t r, uint32_t qb, uint32_t vw, uint32_t bs_b,
+                                                 const correct_params &prm)
+{
+    const uint32_t cyc = (uint32_t)prm.cycle;
+    const int32_t Q = (int32_t)(q1 - qb);
+    const int32_t x = (int32_t)r - (int32_t)vw;
+    const uint32_t ax2 = 2u * (uint32_t)(x < 0 ? -x : x);
+    int32_t k;
+    if (ax2 < cyc) k = Q;
+    else if (ax2 > cyc) k = x > 0 ? Q + 1 : Q - 1;
+    else { const int32_t base = x > 0 ? Q : Q - 1; k = (base & 1) ? base + 1 : base; }
+    const int32_t v = (int32_t)bs_b + k;
+    return (prm.mod_base & (prm.mod_base - 1)) == 0 ? (v & (prm.mod_base - 1)) : pymod(v, prm.mod_base);
+}
+
 // Given lo = number of table phases below r: pick between the circular neighbours, apply the tolerance
 // and round.  Returns true and the corrected BS when a baseline qualifies.
 template <typename RB, typename PAY>
@@ -367,16 +385,7 @@ __device__ __forceinline__ bool decide_phase(const RB *rb, const PAY *pay, uint3
         if (rp_ < rs_ || wp.x < ws_.x) { ws_ = wp; resid = rp_; vw = vp; }      // ties: the earlier baseline
     }
     if ((int64_t)resid > (int64_t)prm.tol) return false;
-    // d = clk - clk_b = Q*cycle + x with |x| < cycle; k = round-half-even(d / cycle)
-    const int32_t Q = (int32_t)(q1 - ws_.y);
-    const int32_t x = (int32_t)r - (int32_t)vw;
-    const uint32_t ax2 = 2u * (uint32_t)(x < 0 ? -x : x);
-    int32_t k;
-    if (ax2 < cyc) k = Q;
-    else if (ax2 > cyc) k = x > 0 ? Q + 1 : Q - 1;
-    else { const int32_t base = x > 0 ? Q : Q - 1; k = (base & 1) ? base + 1 : base; }
-    const int32_t v = (int32_t)ws_.z + k;
-    *out_bs = (prm.mod_base & (prm.mod_base - 1)) == 0 ? (v & (prm.mod_base - 1)) : pymod(v, prm.mod_base);
+    *out_bs = round_to_beam(q1, r, ws_.y, vw, ws_.z, prm);
     return true;
 }
 
@@ -532,126 +541,204 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 // group ids come from the bits k_rows_summarize left per 4 entries, the four rows of a thread search their
 // group's LDS-staged phase table in lock step (fixed trip count over the table padded to a power of two), and a
 // kept row goes straight to the front of its block's entries.
+constexpr int FIN_TPB = 4;            // consecutive blocks of entries one workgroup of k_rows_finish walks
+
+template <typename V, typename T>
+__device__ __forceinline__ void unpack4(const V &q, T v[4])
+{
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint32_t rt_max, const uint32_t *rt_gbase,
                                                       correct_ws ws, correct_params prm, kept_out_t<T8, T32> out,
                                                       uint32_t *stats)
 {
+    using V8 = typename vec4_of<T8>::type;
+    using V32 = typename vec4_of<T32>::type;
     __shared__ uint32_t sh[17];
     __shared__ uint32_t t_rb[TAB_CAP];
     __shared__ uint4 t_pay[TAB_CAP];
     __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
-    const uint32_t f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = blockIdx.y, tile0 = blockIdx.x * FIN_TPB, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
-    const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
-    if (tile * ROWS_PER_BLOCK >= n) return;
+    if (tile0 * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    uint32_t bound = 0, live = 0;
-    T8 fl[4] = {1, 1, 1, 1}, ue[4] = {0, 0, 0, 0};
-    T32 ck[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
-    if (i0 < n) {
-        const uint32_t mk = ws.rmask[(fb + i0) >> 2];
-        bound = mk & 15u;
-        live = mk >> 8;
-        load4(in.flag + fb + i0, fl);
-        load4(in.clk + fb + i0, ck);
-        load4(in.ue + fb + i0, ue);
-        load4(in.rss + fb + i0, rs);
+    // every load of the workgroup's FIN_TPB blocks of entries is issued up front
+    uint32_t mk[FIN_TPB], gb[FIN_TPB + 1];
+    V8 flv[FIN_TPB], uev[FIN_TPB];
+    V32 ckv[FIN_TPB], rsv[FIN_TPB];
+    const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+#pragma unroll
+    for (int j = 0; j < FIN_TPB; j++) {
+        const uint32_t i0 = (tile0 + j) * ROWS_PER_BLOCK + tid * 4;
+        mk[j] = 0;
+        if (i0 < n) {
+            mk[j] = ws.rmask[(fb + i0) >> 2];
+            flv[j] = *reinterpret_cast<const V8 *>(in.flag + fb + i0);
+            ckv[j] = *reinterpret_cast<const V32 *>(in.clk + fb + i0);
+            uev[j] = *reinterpret_cast<const V8 *>(in.ue + fb + i0);
+            rsv[j] = *reinterpret_cast<const V32 *>(in.rss + fb + i0);
+        }
     }
-    // groups this block touches: the one running into it and those starting in it.  Their table descriptors
-    // are fetched while the row loads are in flight (the next block's base gives the count without a scan).
-    const uint32_t gbase = rt_gbase[(size_t)f * rt_max + tile];
-    const uint32_t gnext = (tile + 1) * ROWS_PER_BLOCK < n ? rt_gbase[(size_t)f * rt_max + tile + 1]
-                                                           : stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+#pragma unroll
+    for (int j = 0; j <= FIN_TPB; j++)        // groups started before each block (exclusive bases; G past the end)
+        gb[j] = (tile0 + j) * ROWS_PER_BLOCK < n ? rt_gbase[(size_t)f * rt_max + tile0 + j] : G;
+    // groups the workgroup touches: the one running into it and those starting in it
     const size_t gs = (size_t)f * (in.row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
-    const uint32_t glo = gbase ? gbase - 1 : 0, ghi = gnext - 1;
-    const bool staged = (ghi - glo) < TAB_MAX_GROUPS;
-    if (staged && tid <= ghi - glo) {
-        g_nd[tid] = ws.grp_nd[gs + glo + tid];
-        g_bl[tid] = ws.grp_bl[gs + glo + tid];
+    const uint32_t glo_all = gb[0] ? gb[0] - 1 : 0, ghi_all = gb[FIN_TPB] - 1;
+    const bool staged = (ghi_all - glo_all) < TAB_MAX_GROUPS;
+    if (staged && tid <= ghi_all - glo_all) {
+        g_nd[tid] = ws.grp_nd[gs + glo_all + tid];
+        g_bl[tid] = ws.grp_bl[gs + glo_all + tid];
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);      // also publishes g_nd / g_bl
-    uint32_t gi[4], q1[4], r1[4];
-    int32_t res[4];
-    {
-        uint32_t g = gbase + ex;
+    __syncthreads();
+    uint32_t in_lds_group = 0xFFFFFFFFu, P = 2;          // group whose table sits in t_rb / t_pay, its padded length
+    uint32_t in_reg_group = 0xFFFFFFFFu, t_r = 0xFFFFFFFFu, t_x = 0, t_y = 0, t_z = 0;   // small table: entry `lane`
+    uint32_t pv[7] = {0, 0, 0, 0, 0, 0, 0};              // its entries 7, 15, ..., 55 (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((bound >> k) & 1u) g++;
-            gi[k] = g - 1;
-            res[k] = -1;
-            if (!((live >> k) & 1u)) fl[k] = 1;               // entries that are not rows take no part
-            phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
+    for (int j = 0; j < FIN_TPB; j++) {
+        const uint32_t tile = tile0 + j;
+        if (tile * ROWS_PER_BLOCK >= n) break;
+        const uint32_t bound = mk[j] & 15u, live = mk[j] >> 8;
+        T8 fl[4] = {1, 1, 1, 1}, ue[4] = {0, 0, 0, 0};
+        T32 ck[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
+        if (live) { unpack4(flv[j], fl); unpack4(ckv[j], ck); unpack4(uev[j], ue); unpack4(rsv[j], rs); }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+        const uint32_t glo = gb[j] ? gb[j] - 1 : 0, ghi = gb[j + 1] - 1;
+        uint32_t gi[4], q1[4], r1[4];
+        int32_t res[4];
+        {
+            uint32_t g = gb[j] + ex;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((bound >> k) & 1u) g++;
+                gi[k] = g - 1;
+                res[k] = -1;
+                if (!((live >> k) & 1u)) fl[k] = 1;               // entries that are not rows take no part
+                phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
+            }
         }
-    }
-    uint32_t keep = 0;
-    if (staged) {
-        for (uint32_t gg = glo; gg <= ghi; gg++) {
-            const uint32_t nd = g_nd[gg - glo];
-            if (nd == 0) continue;                              // block-uniform
-            const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo];
-            const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo];
-            if (nd < TAB_CAP) {
-                uint32_t P = 2;                                 // power of two > nd: the padded table length
-                while (P <= nd) P <<= 1;
-                for (uint32_t i = tid; i < P; i += 256) {
-                    t_rb[i] = i < nd ? grb[i] : 0xFFFFFFFFu;
-                    if (i < nd) t_pay[i] = gpay[i];
-                }
-                __syncthreads();
-                uint32_t lo[4] = {0, 0, 0, 0};
-                for (uint32_t h = P >> 1; h; h >>= 1) {
+        uint32_t keep = 0;
+        if (staged) {
+            for (uint32_t gg = glo; gg <= ghi; gg++) {
+                const uint32_t nd = g_nd[gg - glo_all];
+                if (nd == 0) continue;                              // block-uniform
+                const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo_all];
+                const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo_all];
+                if (nd <= 64) {
+                    // the whole table in registers, one entry per lane; lookups are lane permutes (no LDS banks)
+                    if (in_reg_group != gg) {
+                        const uint32_t lane = lane_id();
+                        t_r = lane < nd ? grb[lane] : 0xFFFFFFFFu;
+                        if (lane < nd) { const uint4 q = gpay[lane]; t_x = q.x; t_y = q.y; t_z = q.z; }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
-                }
+                        for (int i = 0; i < 7; i++) pv[i] = (uint32_t)__builtin_amdgcn_readlane((int)t_r, 8 * i + 7);
+                        in_reg_group = gg;
+                    }
+                    // lower bound of every row's phase: the first three levels compare against seven entries held
+                    // in scalar registers, the last four fetch one entry per row and step
+                    uint32_t lo[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (fl[k] == 1 || gi[k] != gg) continue;
-                    int32_t bsn;
-                    if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
-                }
-                __syncthreads();
-            } else {
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r = r1[k];
+                        const bool a = pv[3] < r;                                   // entry 31
+                        const uint32_t m = a ? pv[5] : pv[1];                        // entry 47 : 15
+                        const bool b = m < r;
+                        const uint32_t q = a ? (b ? pv[6] : pv[4]) : (b ? pv[2] : pv[0]);   // entries 55, 39, 23, 7
+                        lo[k] = (a ? 32u : 0u) + (b ? 16u : 0u) + (q < r ? 8u : 0u);
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (fl[k] == 1 || gi[k] != gg) continue;
-                    int32_t bsn;
-                    if (best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                    for (uint32_t h = 4; h; h >>= 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lo[k] += (uint32_t)__shfl((int)t_r, (int)(lo[k] + h - 1), 64) < r1[k] ? h : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) lo[k] += (uint32_t)__shfl((int)t_r, (int)lo[k], 64) < r1[k] ? 1u : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        // all lanes take part in the permutes; rows of other groups drop the result
+                        const uint32_t is = lo[k] < nd ? lo[k] : 0, ip = lo[k] > 0 ? lo[k] - 1 : nd - 1;
+                        const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
+                        const uint32_t cyc = (uint32_t)prm.cycle;
+                        const uint32_t ds_ = vs > r1[k] ? vs - r1[k] : r1[k] - vs, dp_ = vp > r1[k] ? vp - r1[k] : r1[k] - vp;
+                        const uint32_t rs_ = min(ds_, cyc - ds_), rp_ = min(dp_, cyc - dp_);
+                        bool pred = rp_ < rs_;
+                        if (__any(rp_ == rs_)) {                                     // ties: the earlier baseline (rare)
+                            const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
+                            pred = pred || (rp_ == rs_ && xp_ < xs_);
+                        }
+                        const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_, vw = pred ? vp : vs;
+                        const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
+                        if (fl[k] == 1 || gi[k] != gg || (int64_t)resid > (int64_t)prm.tol) continue;
+                        res[k] = round_to_beam(q1[k], r1[k], wq, vw, wb, prm);
+                        keep |= 1u << k;
+                    }
+                } else if (nd < TAB_CAP) {
+                    if (in_lds_group != gg) {                       // consecutive blocks mostly stay in one group
+                        __syncthreads();
+                        P = 2;                                      // power of two > nd: the padded table length
+                        while (P <= nd) P <<= 1;
+                        for (uint32_t i = tid; i < P; i += 256) {
+                            t_rb[i] = i < nd ? grb[i] : 0xFFFFFFFFu;
+                            if (i < nd) t_pay[i] = gpay[i];
+                        }
+                        __syncthreads();
+                        in_lds_group = gg;
+                    }
+                    uint32_t lo[4] = {0, 0, 0, 0};
+                    for (uint32_t h = P >> 1; h; h >>= 1) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (fl[k] == 1 || gi[k] != gg) continue;
+                        int32_t bsn;
+                        if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (fl[k] == 1 || gi[k] != gg) continue;
+                        int32_t bsn;
+                        if (best_phase(grb, gpay, nd, q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (fl[k] == 1) continue;
+                const uint32_t nd = ws.grp_nd[gs + gi[k]];
+                if (nd == 0) continue;
+                int32_t bsn;
+                if (best_phase(ws.srt_rb + bsb + ws.grp_bl[gs + gi[k]], ws.srt_pay + bsb + ws.grp_bl[gs + gi[k]], nd,
+                               q1[k], r1[k], prm, &bsn)) {
+                    res[k] = bsn;
+                    keep |= 1u << k;
                 }
             }
         }
-    } else {
+        uint32_t nk;
+        const uint32_t kx = block_excl_scan(__popc(keep), sh, &nk);
+        size_t o = fb + (size_t)tile * ROWS_PER_BLOCK + kx;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (fl[k] == 1) continue;
-            const uint32_t nd = ws.grp_nd[gs + gi[k]];
-            if (nd == 0) continue;
-            int32_t bsn;
-            if (best_phase(ws.srt_rb + bsb + ws.grp_bl[gs + gi[k]], ws.srt_pay + bsb + ws.grp_bl[gs + gi[k]], nd,
-                           q1[k], r1[k], prm, &bsn)) {
-                res[k] = bsn;
-                keep |= 1u << k;
+            if ((keep >> k) & 1u) {
+                out.ue[o] = ue[k];
+                out.bs[o] = (T8)res[k];
+                out.rss[o] = rs[k];
+                out.clk[o] = ck[k];
+                o++;
             }
         }
-    }
-    uint32_t nk;
-    const uint32_t kx = block_excl_scan(__popc(keep), sh, &nk);
-    size_t o = fb + (size_t)tile * ROWS_PER_BLOCK + kx;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((keep >> k) & 1u) {
-            out.ue[o] = ue[k];
-            out.bs[o] = (T8)res[k];
-            out.rss[o] = rs[k];
-            out.clk[o] = ck[k];
-            o++;
+        if (tid == 0) {
+            out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
+            if (nk) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, nk);
         }
-    }
-    if (tid == 0) {
-        out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
-        if (nk) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, nk);
     }
 }
 
@@ -734,8 +821,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
-        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), grid, block, in, rt_max, ws.rt_nbound, ws, prm, out,
-                    stats);
+        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
+                    rt_max, ws.rt_nbound, ws, prm, out, stats);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,

@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int PIVOT_CHUNK = 65536;     // rows per workgroup of the pivot
+static_assert(PIVOT_CHUNK <= 65536 && PIVOT_CHUNK % 8192 == 0, "packed accumulators count up to 2^16 rows");
 constexpr int MAX_AXIS = 64;
 constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
 
@@ -27,7 +28,7 @@ template <>
 struct v4<int32_t> { using type = int4; };
 
 template <typename T8, typename T32>
-__global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
+__global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
                                                 const uint32_t *stats, int stat_word, const int8_t *beam_to_axis,
                                                 int n_axis, unsigned long long *gsum, uint32_t *gcnt,
                                                 const uint32_t *slot_cnt, uint32_t slot_stride)
@@ -43,36 +44,51 @@ __global__ __launch_bounds__(256) void k_pivot(const T8 *ue, const T8 *bs, const
     const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
     if (r0 >= n) return;
     const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
-    for (int i = tid; i < n_axis * LSTRIDE; i += 256) acc[i] = 0;
+    for (int i = tid; i < n_axis * LSTRIDE; i += 1024) acc[i] = 0;
     if (tid < 64) b2a[tid] = beam_to_axis[tid];
     __syncthreads();
     const size_t fb = (size_t)f * row_cap;
-    for (uint32_t i0 = r0 + tid * 4; i0 < r1; i0 += 1024) {
-        using V8 = typename v4<T8>::type;
-        using V32 = typename v4<T32>::type;
-        uint32_t lim = r1;                     // slotted rows: only the front of each block of entries is used
-        if (slot_cnt) {
-            const uint32_t T = i0 / ROWS_PER_BLOCK;
-            lim = T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T];
-            if (i0 >= lim) continue;
-        }
-        V8 u = *reinterpret_cast<const V8 *>(ue + fb + i0);
-        V8 b = *reinterpret_cast<const V8 *>(bs + fb + i0);
-        V32 r = *reinterpret_cast<const V32 *>(rss + fb + i0);
-        const int64_t uu[4] = {(int64_t)u.x, (int64_t)u.y, (int64_t)u.z, (int64_t)u.w};
-        const int64_t bb[4] = {(int64_t)b.x, (int64_t)b.y, (int64_t)b.z, (int64_t)b.w};
-        const int64_t rr[4] = {(int64_t)r.x, (int64_t)r.y, (int64_t)r.z, (int64_t)r.w};
+    using V8 = typename v4<T8>::type;
+    using V32 = typename v4<T32>::type;
+    // two groups of four entries per thread and step, loads first so both are in flight together
+    for (uint32_t base = r0 + tid * 4; base < r1; base += 8192) {
+        uint32_t lim[2];
+        V8 u[2], b[2];
+        V32 r[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k >= lim) break;
-            if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
-            int c = b2a[uu[k]], rw = b2a[bb[k]];
-            if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
-            atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << 47));
+        for (int h = 0; h < 2; h++) {
+            const uint32_t i0 = base + 4096u * h;
+            lim[h] = 0;
+            if (i0 >= r1) continue;
+            lim[h] = r1;                       // slotted rows: only the front of each block of entries is used
+            if (slot_cnt) {
+                const uint32_t T = i0 / ROWS_PER_BLOCK;
+                lim[h] = min(r1, T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T]);
+            }
+            if (i0 >= lim[h]) continue;
+            u[h] = *reinterpret_cast<const V8 *>(ue + fb + i0);
+            b[h] = *reinterpret_cast<const V8 *>(bs + fb + i0);
+            r[h] = *reinterpret_cast<const V32 *>(rss + fb + i0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t i0 = base + 4096u * h;
+            if (i0 >= lim[h]) continue;
+            const int64_t uu[4] = {(int64_t)u[h].x, (int64_t)u[h].y, (int64_t)u[h].z, (int64_t)u[h].w};
+            const int64_t bb[4] = {(int64_t)b[h].x, (int64_t)b[h].y, (int64_t)b[h].z, (int64_t)b[h].w};
+            const int64_t rr[4] = {(int64_t)r[h].x, (int64_t)r[h].y, (int64_t)r[h].z, (int64_t)r[h].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + k >= lim[h]) break;
+                if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
+                int c = b2a[uu[k]], rw = b2a[bb[k]];
+                if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
+                atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << 47));
+            }
         }
     }
     __syncthreads();
-    for (int i = tid; i < n_axis * n_axis; i += 256) {
+    for (int i = tid; i < n_axis * n_axis; i += 1024) {
         const unsigned long long a = acc[(i / n_axis) * LSTRIDE + (i % n_axis)];
         if (a >> 47) {
             atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], a & ((1ull << 47) - 1));
@@ -379,7 +395,7 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
     if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
     SLAM_HIP(ctx, hipMemsetAsync(ws.sum, 0, (size_t)F * MAX_CELLS * 8, ctx->stream));
     SLAM_HIP(ctx, hipMemsetAsync(ws.cnt, 0, (size_t)F * MAX_CELLS * 4, ctx->stream));
-    dim3 grid((row_cap + PIVOT_CHUNK - 1) / PIVOT_CHUNK, F), block(256);
+    dim3 grid((row_cap + PIVOT_CHUNK - 1) / PIVOT_CHUNK, F), block(1024);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
                 rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt, slot_cnt, slot_stride);
     return SLAM_OK;
