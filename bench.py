@@ -171,8 +171,7 @@ def main():
         # algorithmic bytes each kernel must move per frame (its own inputs + outputs, no re-reads)
         alg = {
             "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
-            "rows_summarize": 6.0 * valid,                   # ue, flag, rss
-            "rows_groups": 6.0 * valid,
+            "tile_groups": 0.5 * valid,                      # 12 bits per 4 entries
             "rows_finish": 10.0 * valid + 10.0 * kept,       # flag, ue, rss, clk in; kept rows out
             "pivot": 6.0 * kept,
             "raster": float(tile_bytes),

@@ -589,7 +589,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[5], cw[16], rw[5], tc;
+    size_t fw[5], cw[16], rw[5], tc, tb[3];
     uint32_t nt_max, st_max, bl_cap;
     size_t total;
 };
@@ -604,6 +604,9 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
                          "slam_batch: row_cap must be a multiple of 16 and >= slam_row_tiles(...) * SLAM_TILE_SLOTS");
     ws_plan p;
     bp.tc = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
+    bp.tb[0] = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
+    bp.tb[1] = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
+    bp.tb[2] = p.add((size_t)bt->n_frames * bp.st_max * BL_PAY_CAP * sizeof(unsigned long long));
     bp.nt_max = frame_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
     bp.bl_cap = correct_ws::default_bl_cap(bt->row_cap);
     frame_ws::plan(p, bt->n_frames, bp.nt_max, bp.fw);
@@ -648,6 +651,13 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     rws.bind(b, bp.rw);
     uint32_t *tile_cnt = bt->tile_cnt_dev ? bt->tile_cnt_dev : (uint32_t *)(b + bp.tc);
     rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap, tile_cnt, bp.st_max};
+    tile_bits tbits;
+    tbits.rmask = cws.rmask;
+    tbits.nbound = (uint32_t *)(b + bp.tb[0]);
+    tbits.nbase = (uint32_t *)(b + bp.tb[1]);
+    tbits.pay = (unsigned long long *)(b + bp.tb[2]);
+    tbits.stride = bp.st_max;
+    if (stages & 2u) rows.bits = tbits;          // the framing pass leaves the correction's per-tile bits
     if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
          (uintptr_t)bt->clk_dev) & 15u)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays must be 16-byte aligned");
@@ -662,6 +672,8 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if (stages & 2u) {
         rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap,
                                         tile_cnt, bp.st_max};
+        in.bits = tbits;
+        in.bits_fresh = (stages & 1u) ? 1 : 0;
         kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev,
                                           kept_cnt, kept_stride};
         if (bt->cycle <= 0 || bt->cycle > (1 << 30)) return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");

@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, u
 // a/b are scanned together (b may be null).  In group mode also writes the group-table sentinels.
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, uint32_t rt_max, uint32_t *stats,
                                                      int stat_a, int stat_b, int keep_stat_b,
-                                                     uint32_t *grp_row, uint32_t *grp_bl, uint32_t grp_stride)
+                                                     uint32_t *grp_row, uint32_t *grp_bl, uint32_t grp_stride,
+                                                     uint32_t unit)
 {
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
-    const uint32_t nt = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const uint32_t nt = (n + unit - 1) / unit;          // counts are per `unit` entries
     uint32_t ca = 0, cb = 0;
     for (uint32_t seg = 0; seg < nt; seg += 1024) {
         uint32_t t = seg + tid;
@@ -224,6 +225,130 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
             j++;
         }
         if (gid_out) gid_out[fb + i] = (int32_t)(g - 1);
+    }
+}
+
+// ---- per framing tile: bits from the row arrays, group table and baseline list from the bits ---------------
+
+// The same bits the single-pass framing kernel leaves (tile_bits), computed from the row arrays: for every tile
+// of a frame the framing fallback decoded (all == 0: only those, and tiles the framing kernel flagged), or for
+// every tile (all == 1).  One wave per tile, one entry per lane and pass.
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats)
+{
+    const uint32_t f = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    const frame_span sp = span_of(in, f, stats);
+    if ((size_t)t * SLOT_ROWS >= sp.n) return;
+    const size_t tix = (size_t)f * in.bits.stride + t;
+    if (!all && !stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS] && !(in.bits.nbase[tix] & TILE_NEEDS_BITS)) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    const uint32_t C = sp.cnt[t];
+    uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
+    unsigned long long *pay = in.bits.pay + tix * BL_PAY_CAP;
+    uint32_t nbound = 0, nbase = 0;
+    for (uint32_t ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
+        const uint32_t e = lane + 64u * ps, i = t * SLOT_ROWS + e;
+        const bool live = e < C;
+        bool b = false, bl = false;
+        uint32_t pck = 0, bsv = 0;
+        if (live) {
+            uint32_t prev = i - 1;
+            if (e == 0) {                              // last row of the nearest earlier tile that has one
+                prev = NO_ROW;
+                for (uint32_t tt = t; tt > 0;) {
+                    --tt;
+                    const uint32_t cc = sp.cnt[tt];
+                    if (cc) { prev = tt * SLOT_ROWS + cc - 1; break; }
+                }
+            }
+            const uint32_t uev = (uint32_t)in.ue[fb + i], flg = (uint32_t)in.flag[fb + i];
+            const uint32_t rsv = (uint32_t)in.rss[fb + i];
+            bsv = (uint32_t)in.bs[fb + i];
+            if (prev == NO_ROW) {
+                b = true;
+            } else {
+                const uint32_t pue = (uint32_t)in.ue[fb + prev], pfl = (uint32_t)in.flag[fb + prev];
+                const uint32_t prs = (uint32_t)in.rss[fb + prev];
+                pck = (uint32_t)in.clk[fb + prev];
+                b = pue > uev;
+                bl = !b && flg == 1u && pfl == 0u && rsv == prs;
+            }
+        }
+        const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
+        if (bl) {
+            const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+            pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
+        }
+        nbound += (uint32_t)__popcll(bm);
+        nbase += (uint32_t)__popcll(lm);
+        const uint32_t grp = 16u * ps + lane;
+        if (lane < 16 && grp < SLOT_ROWS / 4)
+            rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
+                                 (((vm >> (4 * lane)) & 15u) << 8));
+    }
+    if (lane == 0) {
+        in.bits.nbound[tix] = nbound;
+        in.bits.nbase[tix] = nbase;
+    }
+}
+
+// From the per-tile bits and the scanned per-tile bases: group table, baseline list in row order, and the number of
+// groups started before every ROWS_PER_BLOCK-entry block (what k_rows_finish indexes by).  One wave per tile.
+template <typename T8, typename T32>
+__global__ __launch_bounds__(256) void k_tile_groups(rows_in_t<T8, T32> in, correct_ws ws, uint32_t rt_max,
+                                                      uint32_t *rt_gbase, const uint32_t *stats)
+{
+    constexpr uint32_t NG = SLOT_ROWS / 4;                  // 69 four-entry groups per tile
+    __shared__ uint32_t pre[4][NG + 3];                     // per group: baselines before it in the tile << 4 | its baseline bits
+    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, t = blockIdx.x * 4 + wv, lane = lane_id();
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
+    if ((size_t)t * SLOT_ROWS >= n) return;
+    const size_t fb = (size_t)f * in.row_cap;
+    const size_t tix = (size_t)f * in.bits.stride + t;
+    const uint32_t gb = in.bits.nbound[tix], bb = in.bits.nbase[tix];       // exclusive bases after the scan
+    const uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
+    const size_t gs = (size_t)f * (in.row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+    uint32_t cg = 0, cbl = 0;                               // groups / baselines of the tile before this pass
+    for (uint32_t ps = 0; ps < (NG + 63) / 64; ps++) {
+        const uint32_t g = lane + 64u * ps;
+        uint32_t bound = 0, base = 0;
+        if (g < NG) {
+            const uint32_t mk = rm[g];
+            bound = mk & 15u;
+            base = (mk >> 4) & 15u;
+        }
+        const uint32_t packed = __popc(bound) | (__popc(base) << 16);
+        const uint32_t inc = wave_incl_scan(packed);
+        uint32_t eg = cg + ((inc - packed) & 0xFFFFu), eb = cbl + ((inc - packed) >> 16);
+        if (g < NG) {
+            pre[wv][g] = (eb << 4) | base;
+            const uint32_t i0 = t * SLOT_ROWS + 4u * g;
+            if ((i0 % ROWS_PER_BLOCK) == 0) rt_gbase[(size_t)f * rt_max + i0 / ROWS_PER_BLOCK] = gb + eg;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((bound >> k) & 1u) {
+                    ws.grp_row[gs + gb + eg] = i0 + k;
+                    ws.grp_bl[gs + gb + eg] = bb + eb;      // a group's first row is never a baseline
+                    eg++;
+                }
+                if ((base >> k) & 1u) eb++;
+            }
+        }
+        const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
+        cg += tot & 0xFFFFu;
+        cbl += tot >> 16;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long *pay = in.bits.pay + tix * BL_PAY_CAP;
+    for (uint32_t e = lane; e < cbl; e += 64) {
+        const unsigned long long p = pay[e];
+        const uint32_t slot = (uint32_t)(p >> 40), w = pre[wv][slot >> 2];
+        const uint32_t j = bb + (w >> 4) + __popc(w & ((1u << (slot & 3u)) - 1u));
+        ws.bl_clk[bsb + j] = (int32_t)(uint32_t)p;
+        ws.bl_bs[bsb + j] = (int32_t)((p >> 32) & 0xFFu);
     }
 }
 
@@ -811,10 +936,29 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     TC *corr = reinterpret_cast<TC *>(ws.corr);
     const int og = (prm.one_group || prm.explicit_baselines ? 1 : 0) | (prm.explicit_baselines ? 2 : 0);
     const int keep_bl = prm.explicit_baselines ? 1 : 0;
+    if (in.slot_cnt && in.bits.rmask && out.slot_cnt && !og) {
+        // bits per framing tile (left by the framing pass, completed here) -> scan over tiles -> tables -> fused
+        // correction; the per-block summarize / groups kernels are not needed
+        const uint32_t st_max = in.bits.stride;
+        if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
+        dim3 tgrid((st_max + 3) / 4, F);
+        correct_ws w2 = ws;
+        w2.rmask = in.bits.rmask;
+        SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), tgrid, block, in, in.bits_fresh ? 0 : 1, stats);
+        SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), in.bits.nbound, in.bits.nbase, st_max, stats,
+                    (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, 0, ws.grp_row, ws.grp_bl, in.row_cap + 1,
+                    (uint32_t)SLOT_ROWS);
+        SLAM_LAUNCH(ctx, "tile_groups", (k_tile_groups<T8, T32>), tgrid, block, in, w2, rt_max, ws.rt_nbound, stats);
+        SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), w2, in.row_cap, prm, stats);
+        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
+                    rt_max, ws.rt_nbound, w2, prm, out, stats);
+        return SLAM_OK;
+    }
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws.rmask, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
-                (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1);
+                (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1,
+                (uint32_t)ROWS_PER_BLOCK);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), ws, in.row_cap, prm, stats);
@@ -828,7 +972,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
                 corr, prm, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,
-                (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+                (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ROWS_PER_BLOCK);
     if (out.ue) {
         SLAM_LAUNCH(ctx, "rows_emit_kept", (k_rows_emit_kept<T8, T32, TC>), grid, block, in, rt_max, corr,
                     ws.rt_nkept, out, stats);

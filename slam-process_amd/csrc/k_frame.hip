@@ -595,6 +595,7 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     __shared__ __attribute__((aligned(16))) uint32_t stage[4][STAGE_DW];
+    __shared__ uint32_t prevrec[4][4];          // per wave: the record before the tile's first (clk, rss, ue | flag << 8, state)
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
     uint32_t *st = stats + f * SLAM_STAT_WORDS;
     if (st[SLAM_STAT_TWO_PASS]) return;
@@ -612,8 +613,9 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
 
         run_masks m = make_masks(tile, (int64_t)sv.nb - ((int64_t)t * SLOT_TILE - FRAME_RUN) - (int64_t)lane * FRAME_RUN);
         uint32_t x;
+        const uint64_t vall = closure(0x7FFull, m);
         {
-            const uint64_t exits = closure(0x7FFull, m) >> FRAME_RUN;
+            const uint64_t exits = vall >> FRAME_RUN;
             x = __popcll(exits) == 1 ? (uint32_t)__builtin_ctzll(exits) : UNK;
         }
         if (lane == 0) {
@@ -629,6 +631,17 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
         accd += lane ? count_disc(v, m) : 0u;
         uint32_t li = inc - cnt;
         const uint32_t lane_byte = lane * FRAME_RUN;
+        if (lane == 0) {
+            // The record before the tile's first one, for the group / baseline tests: the last record start of
+            // the look-behind run.  Orbits from all 11 entry offsets have merged by position 21, so a start at or
+            // after it is on the scan's own orbit; an earlier one (or none) is not trusted and the tile's bits
+            // are recomputed from the row arrays later.  Tile 0 has nothing before it.
+            const uint64_t hs = vall & m.ok;
+            const uint32_t last = hs ? 63u - (uint32_t)__builtin_clzll(hs) : 0u;
+            uint32_t state = t == 0 ? 2u : ((hs && last >= 21u) ? 1u : 0u);
+            if (state == 1u) starts = 1ull << last;
+            prevrec[wv][3] = state;
+        }
         while (starts) {
             uint32_t p = (uint32_t)__builtin_ctzll(starts);
             starts &= starts - 1;
@@ -637,13 +650,22 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
             uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
             uint32_t d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
             uint32_t d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-            stg[li] = ((d0 >> 24) & 63u) | ((d1 & 63u) << 6) | (((d1 >> 8) & 63u) << 12) |
-                      (((d1 >> 16) & 63u) << 18) | (((d1 >> 24) & 63u) << 24);
-            stg[SLOT_ROWS + li] = (d2 & 63u) | (((d2 >> 8) & 63u) << 6) | (((d2 >> 16) & 63u) << 12);
-            stg8[li] = (uint8_t)((m.cc >> p) & 1u);
-            stg8[SLOT_ROWS + li] = (uint8_t)((d0 >> 8) & 63u);
-            stg8[2 * SLOT_ROWS + li] = (uint8_t)((d0 >> 16) & 63u);
-            li++;
+            const uint32_t clk = ((d0 >> 24) & 63u) | ((d1 & 63u) << 6) | (((d1 >> 8) & 63u) << 12) |
+                                 (((d1 >> 16) & 63u) << 18) | (((d1 >> 24) & 63u) << 24);
+            const uint32_t rss = (d2 & 63u) | (((d2 >> 8) & 63u) << 6) | (((d2 >> 16) & 63u) << 12);
+            const uint32_t flg = (uint32_t)((m.cc >> p) & 1u), uev = (d0 >> 8) & 63u;
+            if (lane == 0) {
+                prevrec[wv][0] = clk;
+                prevrec[wv][1] = rss;
+                prevrec[wv][2] = uev | (flg << 8);
+            } else {
+                stg[li] = clk;
+                stg[SLOT_ROWS + li] = rss;
+                stg8[li] = (uint8_t)flg;
+                stg8[SLOT_ROWS + li] = (uint8_t)uev;
+                stg8[2 * SLOT_ROWS + li] = (uint8_t)((d0 >> 16) & 63u);
+                li++;
+            }
         }
         wave_lds_sync();
         // whole slot block of the tile, full-width stores (slots past the tile's count hold leftovers)
@@ -668,6 +690,55 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
                 gb[64 + lane] = s1[2 * Q + 64 + lane];
             }
             if (lane == 63) out.slot_cnt[(size_t)f * out.slot_stride + t] = inc;
+        }
+        if (out.bits.rmask) {
+            // Group starts (UE drops, _detect_groups bs_beam_correction.py:43-47) and baselines (FLAG 0 -> 1 with
+            // equal RSS inside a group, _identify_baselines :50-61) of the tile's rows, one entry per lane and
+            // pass, from the staged columns; ballots give the bits of 16 four-entry groups at a time.
+            const uint32_t C = (uint32_t)__shfl((int)inc, 63, 64);
+            const uint32_t pstate = prevrec[wv][3];
+            const size_t tix = (size_t)f * out.bits.stride + t;
+            uint16_t *rm = out.bits.rmask + (((size_t)f * out.row_cap + (size_t)t * SLOT_ROWS) >> 2);
+            unsigned long long *pay = out.bits.pay + tix * BL_PAY_CAP;
+            uint32_t nbound = 0, nbase = 0;
+#pragma unroll
+            for (int ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
+                const uint32_t e = lane + 64u * ps;
+                const bool live = e < C;
+                bool b = false, bl = false;
+                uint32_t pck = 0, bsv = 0;
+                if (live) {
+                    const uint32_t uev = stg8[SLOT_ROWS + e], flg = stg8[e], rsv = stg[SLOT_ROWS + e];
+                    uint32_t pue, pfl, prs;
+                    bool first = false, known = true;
+                    if (e > 0) {
+                        pue = stg8[SLOT_ROWS + e - 1]; pfl = stg8[e - 1]; prs = stg[SLOT_ROWS + e - 1]; pck = stg[e - 1];
+                    } else {
+                        pck = prevrec[wv][0]; prs = prevrec[wv][1];
+                        pue = prevrec[wv][2] & 0xFFu; pfl = prevrec[wv][2] >> 8;
+                        first = pstate == 2u;
+                        known = pstate != 0u;
+                    }
+                    b = known && (first || pue > uev);
+                    bl = known && !b && flg == 1u && pfl == 0u && rsv == prs;
+                    bsv = stg8[2 * SLOT_ROWS + e];
+                }
+                const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
+                if (bl) {
+                    const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                    pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
+                }
+                nbound += (uint32_t)__popcll(bm);
+                nbase += (uint32_t)__popcll(lm);
+                const uint32_t grp = 16u * ps + lane;                     // lanes 0..15: one 4-entry group each
+                if (lane < 16 && grp < SLOT_ROWS / 4)
+                    rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
+                                         (((vm >> (4 * lane)) & 15u) << 8));
+            }
+            if (lane == 0) {
+                out.bits.nbound[tix] = nbound;
+                out.bits.nbase[tix] = nbase | ((pstate == 0u && C > 0u) ? TILE_NEEDS_BITS : 0u);
+            }
         }
         accv += cnt;
         wave_lds_sync();

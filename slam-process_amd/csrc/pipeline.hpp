@@ -42,6 +42,21 @@ struct frame_ws {               // device scratch of the framing stage
     void bind(uint8_t *base, const size_t off[5], uint32_t nt_max);
 };
 
+// What the correction needs to know about neighbouring rows, produced per framing tile while the tile's records
+// are still on chip (single-pass framing) or from the row arrays (k_tile_bits):
+//   rmask   per 4 entries: group-start bits | baseline bits << 4 | is-a-row bits << 8 (frame f at f*row_cap/4)
+//   nbound / nbase  per tile: rows that start a group / are baselines (bit 31 of nbase: the tile's bits must
+//           be recomputed from the row arrays because the row before its first row was not at hand)
+//   pay     per tile up to BL_PAY_CAP baselines, any order: clk of the row before | bs << 32 | entry in tile << 40
+constexpr uint32_t BL_PAY_CAP = SLOT_ROWS / 2 + 2;       // a baseline needs a FLAG 0 -> 1 step: at most every 2nd row
+constexpr uint32_t TILE_NEEDS_BITS = 0x80000000u;
+struct tile_bits {
+    uint16_t *rmask = nullptr;
+    uint32_t *nbound = nullptr, *nbase = nullptr;          // [F * stride]
+    unsigned long long *pay = nullptr;                     // [F * stride * BL_PAY_CAP]
+    uint32_t stride = 0;
+};
+
 // Decoded records, frame f at f*row_cap.  Two layouts:
 //   dense   (slot_cnt == nullptr): records 0..VALID-1 in order;
 //   slotted (slot_cnt != nullptr): the records that start in data bytes [t*SLOT_TILE, (t+1)*SLOT_TILE) occupy
@@ -52,6 +67,7 @@ struct rows_out {
     uint32_t row_cap;
     uint32_t *slot_cnt = nullptr;
     uint32_t slot_stride = 0;
+    tile_bits bits;             // slotted layout only; bits.rmask == nullptr: not wanted
 };
 
 // Decode F frames: source -> records + stats words NBYTES / NOT_STRICT / VALID / DISCARDED.
@@ -74,6 +90,8 @@ struct rows_in_t {
     uint32_t row_cap;           // per-frame stride
     const uint32_t *slot_cnt = nullptr;   // slotted layout (see rows_out); nullptr = dense
     uint32_t slot_stride = 0;
+    tile_bits bits;                       // slotted layout: per-tile bits (rmask == nullptr: use the per-block kernels)
+    int bits_fresh = 0;                   // 1: the framing pass of this call filled `bits` (except flagged tiles / frames)
 };
 
 // Kept (corrected) rows.  slot_cnt == nullptr: dense, in order.  Otherwise the kept rows among the entries

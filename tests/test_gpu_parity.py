@@ -353,8 +353,9 @@ def _hostile_streams():
     return out
 
 
+@pytest.mark.parametrize("split_stages", [False, True])
 @pytest.mark.parametrize("two_pass", [False, True])
-def test_batched_bytes_hostile_streams(mapping, lut, two_pass, monkeypatch):
+def test_batched_bytes_hostile_streams(mapping, lut, two_pass, split_stages, monkeypatch):
     import torch
     from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
     if two_pass:
@@ -371,7 +372,11 @@ def test_batched_bytes_hostile_streams(mapping, lut, two_pass, monkeypatch):
     text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
     pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
     pipe.set_layout(offs, lens)
-    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    if split_stages:                   # the correction then rebuilds its per-tile bits from the row arrays
+        pipe.run(text, stages=STAGE_DECODE)
+        pipe.run(text, stages=STAGE_CORRECT)
+    else:
+        pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
     st = pipe.stats_host()
     for f, sbytes in enumerate(streams):
         by = np.frombuffer(sbytes, np.uint8)
