@@ -236,59 +236,67 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats)
 {
-    const uint32_t f = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    const uint32_t f = blockIdx.y, lane = lane_id();
     const frame_span sp = span_of(in, f, stats);
-    if ((size_t)t * SLOT_ROWS >= sp.n) return;
-    const size_t tix = (size_t)f * in.bits.stride + t;
-    if (!all && !stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS] && !(in.bits.nbase[tix] & TILE_NEEDS_BITS)) return;
+    const uint32_t nt = sp.n / SLOT_ROWS;                           // tiles the frame spans
+    // every lane looks at one tile; the wave then works through the tiles that need it, one at a time
+    const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const bool whole = all || stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS];
+    const bool mine = tl < nt && (whole || (in.bits.nbase[(size_t)f * in.bits.stride + tl] & TILE_NEEDS_BITS));
+    uint64_t todo = __ballot(mine);
     const size_t fb = (size_t)f * in.row_cap;
-    const uint32_t C = sp.cnt[t];
-    uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
-    unsigned long long *pay = in.bits.pay + tix * BL_PAY_CAP;
-    uint32_t nbound = 0, nbase = 0;
-    for (uint32_t ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
-        const uint32_t e = lane + 64u * ps, i = t * SLOT_ROWS + e;
-        const bool live = e < C;
-        bool b = false, bl = false;
-        uint32_t pck = 0, bsv = 0;
-        if (live) {
-            uint32_t prev = i - 1;
-            if (e == 0) {                              // last row of the nearest earlier tile that has one
-                prev = NO_ROW;
-                for (uint32_t tt = t; tt > 0;) {
-                    --tt;
-                    const uint32_t cc = sp.cnt[tt];
-                    if (cc) { prev = tt * SLOT_ROWS + cc - 1; break; }
+    while (todo) {
+        const uint32_t t = tl - lane + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const size_t tix = (size_t)f * in.bits.stride + t;
+        const uint32_t C = sp.cnt[t];
+        uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
+        unsigned long long *pay = in.bits.pay + tix * BL_PAY_CAP;
+        uint32_t nbound = 0, nbase = 0;
+        for (uint32_t ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
+            const uint32_t e = lane + 64u * ps, i = t * SLOT_ROWS + e;
+            const bool live = e < C;
+            bool b = false, bl = false;
+            uint32_t pck = 0, bsv = 0;
+            if (live) {
+                uint32_t prev = i - 1;
+                if (e == 0) {                              // last row of the nearest earlier tile that has one
+                    prev = NO_ROW;
+                    for (uint32_t tt = t; tt > 0;) {
+                        --tt;
+                        const uint32_t cc = sp.cnt[tt];
+                        if (cc) { prev = tt * SLOT_ROWS + cc - 1; break; }
+                    }
+                }
+                const uint32_t uev = (uint32_t)in.ue[fb + i], flg = (uint32_t)in.flag[fb + i];
+                const uint32_t rsv = (uint32_t)in.rss[fb + i];
+                bsv = (uint32_t)in.bs[fb + i];
+                if (prev == NO_ROW) {
+                    b = true;
+                } else {
+                    const uint32_t pue = (uint32_t)in.ue[fb + prev], pfl = (uint32_t)in.flag[fb + prev];
+                    const uint32_t prs = (uint32_t)in.rss[fb + prev];
+                    pck = (uint32_t)in.clk[fb + prev];
+                    b = pue > uev;
+                    bl = !b && flg == 1u && pfl == 0u && rsv == prs;
                 }
             }
-            const uint32_t uev = (uint32_t)in.ue[fb + i], flg = (uint32_t)in.flag[fb + i];
-            const uint32_t rsv = (uint32_t)in.rss[fb + i];
-            bsv = (uint32_t)in.bs[fb + i];
-            if (prev == NO_ROW) {
-                b = true;
-            } else {
-                const uint32_t pue = (uint32_t)in.ue[fb + prev], pfl = (uint32_t)in.flag[fb + prev];
-                const uint32_t prs = (uint32_t)in.rss[fb + prev];
-                pck = (uint32_t)in.clk[fb + prev];
-                b = pue > uev;
-                bl = !b && flg == 1u && pfl == 0u && rsv == prs;
+            const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
+            if (bl) {
+                const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
             }
+            nbound += (uint32_t)__popcll(bm);
+            nbase += (uint32_t)__popcll(lm);
+            const uint32_t grp = 16u * ps + lane;
+            if (lane < 16 && grp < SLOT_ROWS / 4)
+                rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
+                                     (((vm >> (4 * lane)) & 15u) << 8));
         }
-        const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
-        if (bl) {
-            const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-            pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
+        if (lane == 0) {
+            in.bits.nbound[tix] = nbound;
+            in.bits.nbase[tix] = nbase;
         }
-        nbound += (uint32_t)__popcll(bm);
-        nbase += (uint32_t)__popcll(lm);
-        const uint32_t grp = 16u * ps + lane;
-        if (lane < 16 && grp < SLOT_ROWS / 4)
-            rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
-                                 (((vm >> (4 * lane)) & 15u) << 8));
-    }
-    if (lane == 0) {
-        in.bits.nbound[tix] = nbound;
-        in.bits.nbase[tix] = nbase;
     }
 }
 
@@ -944,7 +952,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         dim3 tgrid((st_max + 3) / 4, F);
         correct_ws w2 = ws;
         w2.rmask = in.bits.rmask;
-        SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), tgrid, block, in, in.bits_fresh ? 0 : 1, stats);
+        SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), dim3((st_max + 255) / 256, F), block, in,
+                    in.bits_fresh ? 0 : 1, stats);
         SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), in.bits.nbound, in.bits.nbase, st_max, stats,
                     (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, 0, ws.grp_row, ws.grp_bl, in.row_cap + 1,
                     (uint32_t)SLOT_ROWS);

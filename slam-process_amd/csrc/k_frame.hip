@@ -700,41 +700,61 @@ __global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out o
             const size_t tix = (size_t)f * out.bits.stride + t;
             uint16_t *rm = out.bits.rmask + (((size_t)f * out.row_cap + (size_t)t * SLOT_ROWS) >> 2);
             unsigned long long *pay = out.bits.pay + tix * BL_PAY_CAP;
+            constexpr uint32_t NG = SLOT_ROWS / 4;
+            const uint32_t *s1 = stg + 2 * SLOT_ROWS;             // flag dwords [0, NG), ue [NG, 2NG), bs [2NG, 3NG)
             uint32_t nbound = 0, nbase = 0;
 #pragma unroll
-            for (int ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
-                const uint32_t e = lane + 64u * ps;
-                const bool live = e < C;
-                bool b = false, bl = false;
-                uint32_t pck = 0, bsv = 0;
-                if (live) {
-                    const uint32_t uev = stg8[SLOT_ROWS + e], flg = stg8[e], rsv = stg[SLOT_ROWS + e];
-                    uint32_t pue, pfl, prs;
-                    bool first = false, known = true;
-                    if (e > 0) {
-                        pue = stg8[SLOT_ROWS + e - 1]; pfl = stg8[e - 1]; prs = stg[SLOT_ROWS + e - 1]; pck = stg[e - 1];
-                    } else {
-                        pck = prevrec[wv][0]; prs = prevrec[wv][1];
-                        pue = prevrec[wv][2] & 0xFFu; pfl = prevrec[wv][2] >> 8;
-                        first = pstate == 2u;
-                        known = pstate != 0u;
+            for (int ps = 0; ps < (int)((NG + 63) / 64); ps++) {
+                // four entries per lane, byte-parallel: bit 7 of byte k speaks for entry 4g + k
+                const uint32_t g = lane + 64u * ps;
+                uint32_t bnd7 = 0, bas7 = 0, liv7 = 0;
+                if (g < NG && C > 4u * g) {
+                    const uint32_t nl = min(4u, C - 4u * g);
+                    liv7 = nl == 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nl)) - 1u));
+                    const uint32_t flw = s1[g], uew = s1[NG + g];
+                    uint32_t pu, pf;
+                    if (g > 0) { pu = s1[NG + g - 1] >> 24; pf = s1[g - 1] >> 24; }
+                    else if (pstate == 1u) { pu = prevrec[wv][2] & 0xFFu; pf = prevrec[wv][2] >> 8; }
+                    else { pu = 0; pf = 0; }
+                    const uint32_t pvu = (uew << 8) | pu, pvf = (flw << 8) | pf;
+                    bnd7 = ~((uew | 0x80808080u) - pvu) & liv7;                    // previous UE above this one
+                    uint32_t cand = (flw << 7) & ~(pvf << 7) & ~bnd7 & liv7;       // FLAG 1 after FLAG 0, not a group start
+                    if (g == 0) {
+                        if (pstate == 2u) { bnd7 |= 0x80u; cand &= ~0x80u; }       // first row of the frame
+                        else if (pstate == 0u) { bnd7 &= ~0x80u; cand &= ~0x80u; } // row before unknown: redone later
                     }
-                    b = known && (first || pue > uev);
-                    bl = known && !b && flg == 1u && pfl == 0u && rsv == prs;
-                    bsv = stg8[2 * SLOT_ROWS + e];
+                    if (cand) {
+                        const uint4 r4 = reinterpret_cast<const uint4 *>(stg + SLOT_ROWS)[g];
+                        const uint32_t prs = g > 0 ? stg[SLOT_ROWS + 4u * g - 1] : prevrec[wv][1];
+                        const uint32_t eq = (r4.x == prs ? 0x80u : 0u) | (r4.y == r4.x ? 0x8000u : 0u) |
+                                            (r4.z == r4.y ? 0x800000u : 0u) | (r4.w == r4.z ? 0x80000000u : 0u);
+                        bas7 = cand & eq;
+                    }
                 }
-                const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
-                if (bl) {
-                    const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
+                const uint32_t bound = __builtin_amdgcn_udot4(bnd7, 0x08040201u, 0u, false) >> 7;
+                const uint32_t base = __builtin_amdgcn_udot4(bas7, 0x08040201u, 0u, false) >> 7;
+                const uint32_t live = __builtin_amdgcn_udot4(liv7, 0x08040201u, 0u, false) >> 7;
+                if (g < NG) rm[g] = (uint16_t)(bound | (base << 4) | (live << 8));
+                const uint32_t c = __popc(base);                                   // 0, 1 or 2 baselines in four rows
+                const uint64_t m1 = __ballot(c >= 1u), m2 = __ballot(c >= 2u);
+                if (c) {
+                    uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+                    const uint32_t bsw = s1[2 * NG + g];
+                    uint32_t bb = base;
+                    while (bb) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(bb);
+                        bb &= bb - 1;
+                        const uint32_t e = 4u * g + k;
+                        const uint32_t pck = e > 0 ? stg[e - 1] : prevrec[wv][0];
+                        pay[idx++] = (unsigned long long)pck | ((unsigned long long)((bsw >> (8u * k)) & 0xFFu) << 32) |
+                                     ((unsigned long long)e << 40);
+                    }
                 }
-                nbound += (uint32_t)__popcll(bm);
-                nbase += (uint32_t)__popcll(lm);
-                const uint32_t grp = 16u * ps + lane;                     // lanes 0..15: one 4-entry group each
-                if (lane < 16 && grp < SLOT_ROWS / 4)
-                    rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
-                                         (((vm >> (4 * lane)) & 15u) << 8));
+                nbound += __popc(bound);
+                nbase += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
             }
+            nbound = wave_sum(nbound);
             if (lane == 0) {
                 out.bits.nbound[tix] = nbound;
                 out.bits.nbase[tix] = nbase | ((pstate == 0u && C > 0u) ? TILE_NEEDS_BITS : 0u);

@@ -291,34 +291,42 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
     axis_map(edge, h, rp.H, true, ws.rowmap + (size_t)f * rp.H);
 }
 
-// tile[py][px] = cells[rowmap[py]][colmap[px]]; 4 pixels (16 bytes) per thread
+// tile[py][px] = cells[rowmap[py]][colmap[px]].  A thread owns 4 pixel columns (16 bytes per store) of a band of
+// RASTER_BAND pixel rows: its cell columns are looked up once, and the four colours are fetched again only when the
+// band moves to another cell row (a cell covers many pixel rows), so the kernel is a stream of 16-byte stores.
+constexpr int RASTER_BAND = 16;
 __global__ __launch_bounds__(256) void k_raster(const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap,
                                                  int W, int H, const uint32_t *stats, uint8_t *tile)
 {
-    const uint32_t f = blockIdx.y;
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;           // group of 4 pixels
-    const uint32_t wq = (uint32_t)(W + 3) / 4;
-    if (q >= wq * (uint32_t)H) return;
-    const uint32_t py = q / wq, px0 = (q % wq) * 4;
+    const uint32_t f = blockIdx.z;
+    const uint32_t px0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if ((int)px0 >= W) return;
+    const uint32_t y0 = blockIdx.y * RASTER_BAND, y1 = min((uint32_t)H, y0 + RASTER_BAND);
     const uint32_t *st = stats + f * SLAM_STAT_WORDS;
     const bool blank = st[SLAM_STAT_ALLNAN] != 0;
     const int w = (int)st[SLAM_STAT_N_AOA];
-    const uchar4 *c4 = reinterpret_cast<const uchar4 *>(cells) + (size_t)f * MAX_CELLS;
-    uchar4 out[4];
-    const int row = blank ? 0 : rowmap[(size_t)f * H + py];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        out[k] = make_uchar4(255, 255, 255, 0);
-        if (!blank && (int)(px0 + k) < W) out[k] = c4[row * w + colmap[(size_t)f * W + px0 + k]];
-    }
-    uchar4 *dst = reinterpret_cast<uchar4 *>(tile) + ((size_t)f * H + py) * W + px0;
-    if ((W & 3) == 0) {
-        uint4 v;
-        v.x = *reinterpret_cast<uint32_t *>(&out[0]); v.y = *reinterpret_cast<uint32_t *>(&out[1]);
-        v.z = *reinterpret_cast<uint32_t *>(&out[2]); v.w = *reinterpret_cast<uint32_t *>(&out[3]);
-        *reinterpret_cast<uint4 *>(dst) = v;
-    } else {
-        for (int k = 0; k < 4 && (int)(px0 + k) < W; k++) dst[k] = out[k];
+    const uint32_t *c4 = reinterpret_cast<const uint32_t *>(cells) + (size_t)f * MAX_CELLS;
+    int col[4] = {0, 0, 0, 0};
+    const int npx = min(4, W - (int)px0);
+    if (!blank)
+        for (int k = 0; k < npx; k++) col[k] = colmap[(size_t)f * W + px0 + k];
+    const uint32_t none = 0x00FFFFFFu;                          // (255, 255, 255, 0): transparent white
+    uint32_t out[4] = {none, none, none, none};
+    int cur = -1;
+    for (uint32_t py = y0; py < y1; py++) {
+        if (!blank) {
+            const int row = rowmap[(size_t)f * H + py];           // uniform over the workgroup
+            if (row != cur) {
+                cur = row;
+                for (int k = 0; k < npx; k++) out[k] = c4[row * w + col[k]];
+            }
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(tile) + ((size_t)f * H + py) * W + px0;
+        if (npx == 4 && (W & 3) == 0) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+        } else {
+            for (int k = 0; k < npx; k++) dst[k] = out[k];
+        }
     }
 }
 
@@ -433,9 +441,8 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
     if (F == 0) return SLAM_OK;
     SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(1024), rp, ws, kern, ks, matrix, blurred, stats);
     if (tile) {
-        const uint32_t groups = (uint32_t)((rp.W + 3) / 4) * (uint32_t)rp.H;
-        SLAM_LAUNCH(ctx, "raster", k_raster, dim3((groups + 255) / 256, F), dim3(256), ws.cells, ws.colmap,
-                    ws.rowmap, rp.W, rp.H, stats, tile);
+        const dim3 rgrid((uint32_t)((rp.W + 1023) / 1024), (uint32_t)((rp.H + RASTER_BAND - 1) / RASTER_BAND), F);
+        SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), ws.cells, ws.colmap, ws.rowmap, rp.W, rp.H, stats, tile);
     }
     return SLAM_OK;
 }
@@ -459,9 +466,8 @@ int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *ao
     SLAM_LAUNCH(ctx, "render_cells", k_render_only, dim3(1), dim3(256), mat, h, w, aod, aoa, use_log, vmin, vmax,
                 lut, cells, colmap, rowmap, W, H, stats);
     if (tile) {
-        const uint32_t groups = (uint32_t)((W + 3) / 4) * (uint32_t)H;
-        SLAM_LAUNCH(ctx, "raster", k_raster, dim3((groups + 255) / 256, 1), dim3(256), cells, colmap, rowmap, W, H,
-                    stats, tile);
+        const dim3 rgrid((uint32_t)((W + 1023) / 1024), (uint32_t)((H + RASTER_BAND - 1) / RASTER_BAND), 1);
+        SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), cells, colmap, rowmap, W, H, stats, tile);
     }
     return SLAM_OK;
 }
