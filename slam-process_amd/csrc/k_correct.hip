@@ -300,63 +300,69 @@ __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int al
     }
 }
 
-// From the per-tile bits and the scanned per-tile bases: group table, baseline list in row order, and the number of
-// groups started before every ROWS_PER_BLOCK-entry block (what k_rows_finish indexes by).  One wave per tile.
+// From the per-tile bits and the scanned per-tile bases: the group table (first row and first baseline of every
+// group) and the number of groups started before every ROWS_PER_BLOCK-entry block (what k_rows_finish indexes by).
+// Every lane looks at one tile; tiles without a group start need at most the block entry, the few with one are
+// worked through by the whole wave.
 template <typename T8, typename T32>
 __global__ __launch_bounds__(256) void k_tile_groups(rows_in_t<T8, T32> in, correct_ws ws, uint32_t rt_max,
                                                       uint32_t *rt_gbase, const uint32_t *stats)
 {
     constexpr uint32_t NG = SLOT_ROWS / 4;                  // 69 four-entry groups per tile
-    __shared__ uint32_t pre[4][NG + 3];                     // per group: baselines before it in the tile << 4 | its baseline bits
-    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, t = blockIdx.x * 4 + wv, lane = lane_id();
+    const uint32_t f = blockIdx.y, lane = lane_id();
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
-    if ((size_t)t * SLOT_ROWS >= n) return;
+    const uint32_t nt = n / SLOT_ROWS;
+    const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
     const size_t fb = (size_t)f * in.row_cap;
-    const size_t tix = (size_t)f * in.bits.stride + t;
-    const uint32_t gb = in.bits.nbound[tix], bb = in.bits.nbase[tix];       // exclusive bases after the scan
-    const uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
-    const size_t gs = (size_t)f * (in.row_cap + 1);
-    const size_t bsb = (size_t)f * ws.bl_cap;
-    uint32_t cg = 0, cbl = 0;                               // groups / baselines of the tile before this pass
-    for (uint32_t ps = 0; ps < (NG + 63) / 64; ps++) {
-        const uint32_t g = lane + 64u * ps;
-        uint32_t bound = 0, base = 0;
-        if (g < NG) {
-            const uint32_t mk = rm[g];
-            bound = mk & 15u;
-            base = (mk >> 4) & 15u;
+    const uint32_t *nb = in.bits.nbound + (size_t)f * in.bits.stride;       // exclusive bases after the scan
+    const uint32_t *nl = in.bits.nbase + (size_t)f * in.bits.stride;
+    bool work = false;
+    if (tl < nt) {
+        const uint32_t gb = nb[tl];
+        const uint32_t gnext = tl + 1 < nt ? nb[tl + 1] : stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+        work = gnext > gb;
+        if (!work) {                                        // no group starts here: a block that begins in the tile
+            const uint32_t lo = tl * SLOT_ROWS;             // has as many groups before it as the tile
+            const uint32_t bs = (lo + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK * ROWS_PER_BLOCK;
+            if (bs < lo + SLOT_ROWS) rt_gbase[(size_t)f * rt_max + bs / ROWS_PER_BLOCK] = gb;
         }
-        const uint32_t packed = __popc(bound) | (__popc(base) << 16);
-        const uint32_t inc = wave_incl_scan(packed);
-        uint32_t eg = cg + ((inc - packed) & 0xFFFFu), eb = cbl + ((inc - packed) >> 16);
-        if (g < NG) {
-            pre[wv][g] = (eb << 4) | base;
-            const uint32_t i0 = t * SLOT_ROWS + 4u * g;
-            if ((i0 % ROWS_PER_BLOCK) == 0) rt_gbase[(size_t)f * rt_max + i0 / ROWS_PER_BLOCK] = gb + eg;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((bound >> k) & 1u) {
-                    ws.grp_row[gs + gb + eg] = i0 + k;
-                    ws.grp_bl[gs + gb + eg] = bb + eb;      // a group's first row is never a baseline
-                    eg++;
-                }
-                if ((base >> k) & 1u) eb++;
-            }
-        }
-        const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
-        cg += tot & 0xFFFFu;
-        cbl += tot >> 16;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned long long *pay = in.bits.pay + tix * BL_PAY_CAP;
-    for (uint32_t e = lane; e < cbl; e += 64) {
-        const unsigned long long p = pay[e];
-        const uint32_t slot = (uint32_t)(p >> 40), w = pre[wv][slot >> 2];
-        const uint32_t j = bb + (w >> 4) + __popc(w & ((1u << (slot & 3u)) - 1u));
-        ws.bl_clk[bsb + j] = (int32_t)(uint32_t)p;
-        ws.bl_bs[bsb + j] = (int32_t)((p >> 32) & 0xFFu);
+    uint64_t todo = __ballot(work);
+    const size_t gs = (size_t)f * (in.row_cap + 1);
+    while (todo) {
+        const uint32_t t = tl - lane + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t gb = nb[t], bb = nl[t];
+        const uint16_t *rm = in.bits.rmask + ((fb + (size_t)t * SLOT_ROWS) >> 2);
+        uint32_t cg = 0, cbl = 0;                           // groups / baselines of the tile before this pass
+        for (uint32_t ps = 0; ps < (NG + 63) / 64; ps++) {
+            const uint32_t g = lane + 64u * ps;
+            uint32_t bound = 0, base = 0;
+            if (g < NG) {
+                const uint32_t mk = rm[g];
+                bound = mk & 15u;
+                base = (mk >> 4) & 15u;
+            }
+            const uint32_t packed = __popc(bound) | (__popc(base) << 16);
+            const uint32_t inc = wave_incl_scan(packed);
+            uint32_t eg = cg + ((inc - packed) & 0xFFFFu), eb = cbl + ((inc - packed) >> 16);
+            if (g < NG) {
+                const uint32_t i0 = t * SLOT_ROWS + 4u * g;
+                if ((i0 % ROWS_PER_BLOCK) == 0) rt_gbase[(size_t)f * rt_max + i0 / ROWS_PER_BLOCK] = gb + eg;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((bound >> k) & 1u) {
+                        ws.grp_row[gs + gb + eg] = i0 + k;
+                        ws.grp_bl[gs + gb + eg] = bb + eb;  // a group's first row is never a baseline
+                        eg++;
+                    }
+                    if ((base >> k) & 1u) eb++;
+                }
+            }
+            const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
+            cg += tot & 0xFFFFu;
+            cbl += tot >> 16;
+        }
     }
 }
 
@@ -372,11 +378,82 @@ __device__ __forceinline__ void phase_of(int32_t clk, const correct_params &p, u
     *r = n - qq * (uint32_t)p.cycle;
 }
 
+// Baseline j (row order) of frame f out of the per-tile lists; T0..T1 are the tiles of the rows of its group.
+__device__ __forceinline__ unsigned long long baseline_from_tiles(const tile_bits &bits, uint32_t f, uint32_t j,
+                                                                  uint32_t T0, uint32_t T1)
+{
+    const uint32_t *bbase = bits.nbase + (size_t)f * bits.stride;        // baselines before each tile
+    uint32_t lo = T0, hi = T1;                                            // last tile whose base is <= j
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (bbase[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return bits.pay[((size_t)f * bits.stride + lo) * BL_PAY_CAP + (j - bbase[lo])];
+}
+
+constexpr uint32_t WAVE_SORT_MAX = 64;      // groups of up to this many baselines are sorted by one wave in registers
+
+// Groups with at most 64 baselines, one wave per group: bitonic sort of (phase, index) across the lanes with lane
+// exchanges, no LDS and no barriers.  Same outputs as k_bl_sort, which skips these groups when told so.
+__global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t row_cap, correct_params prm,
+                                                        const uint32_t *stats, tile_bits bits)
+{
+    const uint32_t f = blockIdx.y, lane = lane_id();
+    const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+    const size_t gs = (size_t)f * (row_cap + 1);
+    const size_t bsb = (size_t)f * ws.bl_cap;
+    for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < G; g += gridDim.x * 4) {
+        const uint32_t b0 = ws.grp_bl[gs + g], m = ws.grp_bl[gs + g + 1] - b0;
+        if (m == 0) {
+            if (lane == 0) ws.grp_nd[gs + g] = 0;
+            continue;
+        }
+        if (m > WAVE_SORT_MAX) continue;
+        uint32_t q = 0, r = 0, bsv = 0;
+        unsigned long long key = ~0ull;
+        if (lane < m) {
+            int32_t clk;
+            if (bits.pay) {
+                const uint32_t T0 = ws.grp_row[gs + g] / SLOT_ROWS, T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS;
+                const unsigned long long p = baseline_from_tiles(bits, f, b0 + lane, T0, T1);
+                clk = (int32_t)(uint32_t)p;
+                bsv = (uint32_t)((p >> 32) & 0xFFu);
+            } else {
+                clk = ws.bl_clk[bsb + b0 + lane];
+                bsv = (uint32_t)ws.bl_bs[bsb + b0 + lane];
+            }
+            phase_of(clk, prm, &q, &r);
+            key = ((unsigned long long)r << 32) | lane;
+        }
+#pragma unroll
+        for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = shfl64(key, (int)(lane ^ j));
+                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+                key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+            }
+        }
+        // lane i now holds the i-th smallest (phase, index); the first of every phase is kept
+        const uint32_t ph = (uint32_t)(key >> 32), idx = (uint32_t)key;
+        const uint32_t ph_left = (uint32_t)__shfl_up((int)ph, 1, 64);
+        const bool keep = lane < m && (lane == 0 || ph_left != ph);
+        const uint64_t km = __ballot(keep);
+        const uint32_t qi = (uint32_t)__shfl((int)q, (int)(idx & 63u), 64), bi = (uint32_t)__shfl((int)bsv, (int)(idx & 63u), 64);
+        if (keep) {
+            const uint32_t o = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+            ws.srt_rb[bsb + b0 + o] = ph;
+            ws.srt_pay[bsb + b0 + o] = make_uint4(idx, qi, bi, 0);
+        }
+        if (lane == 0) ws.grp_nd[gs + g] = (uint32_t)__popcll(km);
+    }
+}
+
 // Per group: sort baseline phases (clk_b mod cycle), keep the earliest baseline of each phase.
 // Output per distinct phase, ascending: srt_rb = phase, srt_pay = (baseline index in its group,
 // clk_b div cycle, bs_b, 0).
 __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap, correct_params prm,
-                                                  const uint32_t *stats)
+                                                  const uint32_t *stats, tile_bits bits, uint32_t skip_upto)
 {
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ uint32_t sh[17];
@@ -387,9 +464,21 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
         const uint32_t b0 = ws.grp_bl[gs + g], b1 = ws.grp_bl[gs + g + 1];
         const uint32_t m = b1 - b0;
+        if (m <= skip_upto) continue;                       // empty, or sorted by k_bl_sort_small
         if (m == 0) {
             if (tid == 0) ws.grp_nd[gs + g] = 0;
             continue;
+        }
+        if (bits.pay) {
+            // The baselines still sit in per-tile lists (row order inside a tile): write this group's stretch of
+            // the row-ordered list.  Its tiles are those of its rows.
+            const uint32_t T0 = ws.grp_row[gs + g] / SLOT_ROWS, T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS;
+            for (uint32_t i = tid; i < m; i += 256) {
+                const unsigned long long p = baseline_from_tiles(bits, f, b0 + i, T0, T1);
+                ws.bl_clk[bsb + b0 + i] = (int32_t)(uint32_t)p;
+                ws.bl_bs[bsb + b0 + i] = (int32_t)((p >> 32) & 0xFFu);
+            }
+            __syncthreads();
         }
         if (m <= SORT_CAP) {
             uint32_t P = 1;
@@ -949,7 +1038,6 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         // correction; the per-block summarize / groups kernels are not needed
         const uint32_t st_max = in.bits.stride;
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
-        dim3 tgrid((st_max + 3) / 4, F);
         correct_ws w2 = ws;
         w2.rmask = in.bits.rmask;
         SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), dim3((st_max + 255) / 256, F), block, in,
@@ -957,8 +1045,12 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), in.bits.nbound, in.bits.nbase, st_max, stats,
                     (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, 0, ws.grp_row, ws.grp_bl, in.row_cap + 1,
                     (uint32_t)SLOT_ROWS);
-        SLAM_LAUNCH(ctx, "tile_groups", (k_tile_groups<T8, T32>), tgrid, block, in, w2, rt_max, ws.rt_nbound, stats);
-        SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), w2, in.row_cap, prm, stats);
+        SLAM_LAUNCH(ctx, "tile_groups", (k_tile_groups<T8, T32>), dim3((st_max + 255) / 256, F), block, in, w2, rt_max,
+                    ws.rt_nbound, stats);
+        SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), w2, in.row_cap, prm,
+                    stats, in.bits);
+        SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), w2, in.row_cap, prm, stats,
+                    in.bits, WAVE_SORT_MAX);
         SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
                     rt_max, ws.rt_nbound, w2, prm, out, stats);
         return SLAM_OK;
@@ -970,7 +1062,10 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                 (uint32_t)ROWS_PER_BLOCK);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
-    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), ws, in.row_cap, prm, stats);
+    SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), ws, in.row_cap, prm, stats,
+                tile_bits());
+    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), ws, in.row_cap, prm, stats,
+                tile_bits(), WAVE_SORT_MAX);
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");

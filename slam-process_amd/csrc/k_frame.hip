@@ -591,7 +591,8 @@ __device__ __forceinline__ void fill_slot_tile(uint32_t *tile, const src_view &s
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))      // keep 4 waves per SIMD (<= 128 VGPRs)
+void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
     __shared__ __attribute__((aligned(16))) uint32_t stage[4][STAGE_DW];
