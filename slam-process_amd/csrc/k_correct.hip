@@ -782,6 +782,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     __shared__ uint32_t t_rb[TAB_CAP];
     __shared__ uint4 t_pay[TAB_CAP];
     __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
+    __shared__ uint32_t wave_tot[2][4];                   // kept rows per wave, double-buffered over the blocks walked
     const uint32_t f = blockIdx.y, tile0 = blockIdx.x * FIN_TPB, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     if (tile0 * ROWS_PER_BLOCK >= n) return;
@@ -827,8 +828,12 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         T8 fl[4] = {1, 1, 1, 1}, ue[4] = {0, 0, 0, 0};
         T32 ck[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
         if (live) { unpack4(flv[j], fl); unpack4(ckv[j], ck); unpack4(uev[j], ue); unpack4(rsv[j], rs); }
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
+        // rows before this thread's that start a group: none in most blocks (the bases say so without a scan)
+        uint32_t ex = 0;
+        if (gb[j + 1] != gb[j]) {
+            uint32_t tot;
+            ex = block_excl_scan(__popc(bound), sh, &tot);
+        }
         const uint32_t glo = gb[j] ? gb[j] - 1 : 0, ghi = gb[j + 1] - 1;
         uint32_t gi[4], q1[4], r1[4];
         int32_t res[4];
@@ -944,8 +949,20 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                 }
             }
         }
-        uint32_t nk;
-        const uint32_t kx = block_excl_scan(__popc(keep), sh, &nk);
+        // kept rows before this thread's: ballots inside the wave, one exchange of wave totals across the block
+        uint32_t kx = 0, wtot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t bk = __ballot((keep >> k) & 1u);
+            kx += __builtin_amdgcn_mbcnt_hi((uint32_t)(bk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bk, 0u));
+            wtot += (uint32_t)__popcll(bk);
+        }
+        uint32_t *wt = wave_tot[j & 1];
+        if (lane_id() == 0) wt[tid >> 6] = wtot;
+        __syncthreads();
+        const uint32_t w0 = wt[0], w1 = wt[1], w2 = wt[2], w3 = wt[3], wv = tid >> 6;
+        const uint32_t nk = w0 + w1 + w2 + w3;
+        kx += (wv > 0 ? w0 : 0u) + (wv > 1 ? w1 : 0u) + (wv > 2 ? w2 : 0u);
         size_t o = fb + (size_t)tile * ROWS_PER_BLOCK + kx;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
