@@ -783,6 +783,8 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     __shared__ uint4 t_pay[TAB_CAP];
     __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
     __shared__ uint32_t wave_tot[2][4];                   // kept rows per wave, double-buffered over the blocks walked
+    __shared__ __attribute__((aligned(16))) T32 k_rs[ROWS_PER_BLOCK], k_ck[ROWS_PER_BLOCK];   // kept rows of a block, packed
+    __shared__ __attribute__((aligned(16))) T8 k_ue[ROWS_PER_BLOCK], k_bs[ROWS_PER_BLOCK];
     const uint32_t f = blockIdx.y, tile0 = blockIdx.x * FIN_TPB, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     if (tile0 * ROWS_PER_BLOCK >= n) return;
@@ -963,16 +965,28 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         const uint32_t w0 = wt[0], w1 = wt[1], w2 = wt[2], w3 = wt[3], wv = tid >> 6;
         const uint32_t nk = w0 + w1 + w2 + w3;
         kx += (wv > 0 ? w0 : 0u) + (wv > 1 ? w1 : 0u) + (wv > 2 ? w2 : 0u);
-        size_t o = fb + (size_t)tile * ROWS_PER_BLOCK + kx;
+        // the block's kept rows are packed in LDS, then leave as full-width stores (the entries between the count
+        // and the next multiple of four receive leftovers; they are unused slots)
+        {
+            uint32_t o = kx;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((keep >> k) & 1u) {
-                out.ue[o] = ue[k];
-                out.bs[o] = (T8)res[k];
-                out.rss[o] = rs[k];
-                out.clk[o] = ck[k];
-                o++;
+            for (int k = 0; k < 4; k++) {
+                if ((keep >> k) & 1u) {
+                    k_ue[o] = ue[k];
+                    k_bs[o] = (T8)res[k];
+                    k_rs[o] = rs[k];
+                    k_ck[o] = ck[k];
+                    o++;
+                }
             }
+        }
+        __syncthreads();
+        if (tid * 4 < nk) {
+            const size_t ob = fb + (size_t)tile * ROWS_PER_BLOCK + tid * 4;
+            *reinterpret_cast<V8 *>(out.ue + ob) = reinterpret_cast<const V8 *>(k_ue)[tid];
+            *reinterpret_cast<V8 *>(out.bs + ob) = reinterpret_cast<const V8 *>(k_bs)[tid];
+            *reinterpret_cast<V32 *>(out.rss + ob) = reinterpret_cast<const V32 *>(k_rs)[tid];
+            *reinterpret_cast<V32 *>(out.clk + ob) = reinterpret_cast<const V32 *>(k_ck)[tid];
         }
         if (tid == 0) {
             out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
