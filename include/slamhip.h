@@ -41,8 +41,11 @@ typedef struct slam_ctx slam_ctx;
 /* ---- context ------------------------------------------------------------------------- */
 int slam_ctx_create(int device, slam_ctx **out);
 int slam_ctx_destroy(slam_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the ctx's own stream. */
+/* Enqueue on an existing hipStream_t from now on (e.g. torch's current stream).  The handle is taken as is:
+ * NULL is HIP's null stream, which is what torch's default stream is.  A new ctx uses a non-blocking stream
+ * of its own; slam_use_own_stream goes back to it. */
 int slam_set_stream(slam_ctx *ctx, void *hip_stream);
+int slam_use_own_stream(slam_ctx *ctx);
 int slam_sync(slam_ctx *ctx);
 const char *slam_last_error(slam_ctx *ctx);
 const char *slam_version(void);
@@ -161,6 +164,12 @@ typedef struct slam_batch {
     double *matrix_dev;           /* [F*n_axis*n_axis] mean, NaN = empty (full axis grid)         */
     double *blurred_dev;          /* [F*n_axis*n_axis] blurred compact matrix, row stride n_aoa   */
     uint8_t *tile_dev;            /* [F*tile_h*tile_w*4]                                          */
+    /* optional: what the tile is painted from (NULL: kept in the ctx workspace).  tile[py][px] =
+     * cells[rowmap[py] * N_AOA + colmap[px]]; with the frame's stats words these 20 KB reproduce the tile
+     * bit for bit through slam_raster_dev, e.g. on the rank that collects results. */
+    uint8_t *cells_dev;           /* [F*4096*4] RGBA per cell of the compact matrix               */
+    int16_t *colmap_dev;          /* [F*tile_w] pixel column -> cell column                       */
+    int16_t *rowmap_dev;          /* [F*tile_h] pixel row -> cell row                             */
 } slam_batch;
 
 #define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
@@ -193,6 +202,12 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
  * (excel_heatmap_v3.py:519-545) without the xlsx hops between them.
  * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones). */
 int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
+
+/* Paint n_frames tiles from cell colours and pixel->cell maps as slam_process_frames_dev leaves them
+ * (cells_dev / colmap_dev / rowmap_dev / stats_dev of slam_batch, same strides): the last step of
+ * generate_heatmap's mesh (excel_heatmap_v3.py:442-446) on its own.  Device pointers, asynchronous. */
+int slam_raster_dev(slam_ctx *ctx, const uint8_t *cells_dev, const int16_t *colmap_dev, const int16_t *rowmap_dev,
+                    const uint32_t *stats_dev, uint32_t n_frames, int32_t tile_w, int32_t tile_h, uint8_t *tile_dev);
 
 /* Bytes of ctx workspace slam_process_frames_dev needs for this batch shape (it grows the
  * workspace itself on first use; callers that must not allocate later call this once up front). */

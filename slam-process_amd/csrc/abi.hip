@@ -61,7 +61,14 @@ extern "C" int slam_ctx_destroy(slam_ctx *ctx)
 extern "C" int slam_set_stream(slam_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return SLAM_E_INVALID;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;          // NULL is HIP's null stream (e.g. torch's default stream)
+    return SLAM_OK;
+}
+
+extern "C" int slam_use_own_stream(slam_ctx *ctx)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    ctx->stream = ctx->own_stream;
     return SLAM_OK;
 }
 
@@ -616,6 +623,18 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
     return SLAM_OK;
 }
 
+extern "C" int slam_raster_dev(slam_ctx *ctx, const uint8_t *cells_dev, const int16_t *colmap_dev,
+                               const int16_t *rowmap_dev, const uint32_t *stats_dev, uint32_t n_frames,
+                               int32_t tile_w, int32_t tile_h, uint8_t *tile_dev)
+{
+    REQUIRE_CTX(ctx);
+    if (!cells_dev || !colmap_dev || !rowmap_dev || !stats_dev || !tile_dev || tile_w < 1 || tile_h < 1)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_raster_dev: NULL pointer or empty tile");
+    if (((uintptr_t)tile_dev & 15u) || ((uintptr_t)cells_dev & 3u))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_raster_dev: tile must be 16-byte aligned, cells 4-byte aligned");
+    return raster_only(ctx, cells_dev, colmap_dev, rowmap_dev, stats_dev, n_frames, tile_w, tile_h, tile_dev);
+}
+
 extern "C" int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch)
 {
     REQUIRE_CTX(ctx);
@@ -649,6 +668,9 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     cws.bind(b, bp.cw, bp.bl_cap);
     render_ws rws;
     rws.bind(b, bp.rw);
+    if (bt->cells_dev) rws.cells = bt->cells_dev;
+    if (bt->colmap_dev) rws.colmap = bt->colmap_dev;
+    if (bt->rowmap_dev) rws.rowmap = bt->rowmap_dev;
     uint32_t *tile_cnt = bt->tile_cnt_dev ? bt->tile_cnt_dev : (uint32_t *)(b + bp.tc);
     rows_out rows{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap, tile_cnt, bp.st_max};
     tile_bits tbits;

@@ -447,6 +447,15 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
     return SLAM_OK;
 }
 
+int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap, const uint32_t *stats,
+                uint32_t F, int W, int H, uint8_t *tile)
+{
+    if (F == 0) return SLAM_OK;
+    const dim3 rgrid((uint32_t)((W + 1023) / 1024), (uint32_t)((H + RASTER_BAND - 1) / RASTER_BAND), F);
+    SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), cells, colmap, rowmap, W, H, stats, tile);
+    return SLAM_OK;
+}
+
 int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt, int cells, double *matrix)
 {
     SLAM_LAUNCH(ctx, "mean", k_mean_only, dim3((cells + 255) / 256), dim3(256), sum, cnt, cells, matrix);

@@ -172,6 +172,8 @@ int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern,
 int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa, int use_log,
                 double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,
                 int16_t *colmap, int16_t *rowmap, uint32_t *stats);
+int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap, const uint32_t *stats,
+                uint32_t F, int W, int H, uint8_t *tile);
 int slam_gaussian_kernel_host(double sigma, std::vector<double> &k);
 
 // ---- general tokenizer ---------------------------------------------------------------------------

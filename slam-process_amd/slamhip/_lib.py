@@ -23,9 +23,9 @@ STAT_WORDS = 16
 TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
 
 EXPORTS = [
-    "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_sync", "slam_last_error", "slam_version",
+    "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
     "slam_hex_unpack", "slam_parse_records", "slam_parse_text", "slam_correct", "slam_pivot_mean",
-    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_reserve_workspace",
+    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_raster_dev", "slam_reserve_workspace",
     "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
@@ -53,7 +53,7 @@ class Batch(C.Structure):
         ("kept_ue_dev", C.c_void_p), ("kept_bs_dev", C.c_void_p),
         ("kept_rss_dev", C.c_void_p), ("kept_clk_dev", C.c_void_p), ("kept_cnt_dev", C.c_void_p),
         ("stats_dev", C.c_void_p), ("matrix_dev", C.c_void_p), ("blurred_dev", C.c_void_p),
-        ("tile_dev", C.c_void_p),
+        ("tile_dev", C.c_void_p), ("cells_dev", C.c_void_p), ("colmap_dev", C.c_void_p), ("rowmap_dev", C.c_void_p),
     ]
 
 
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
         lib.slam_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
         lib.slam_ctx_destroy.argtypes = [vp]
         lib.slam_set_stream.argtypes = [vp, vp]
+        lib.slam_use_own_stream.argtypes = [vp]
         lib.slam_sync.argtypes = [vp]
         lib.slam_last_error.argtypes = [vp]
         lib.slam_last_error.restype = C.c_char_p
@@ -99,6 +100,7 @@ def load() -> C.CDLL:
                                     C.c_int, C.c_int, vp]
         lib.slam_process_frames_dev.argtypes = [vp, C.POINTER(Batch), u32]
         lib.slam_reserve_workspace.argtypes = [vp, C.POINTER(Batch)]
+        lib.slam_raster_dev.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, vp]
         lib.slam_synth_text_len.argtypes = [u32, u32]
         lib.slam_synth_text_len.restype = sz
         lib.slam_synth_frames_dev.argtypes = [vp, vp, u64, u32, u32, u32, u32, u64]
@@ -135,7 +137,12 @@ class Context:
         return rc
 
     def set_stream(self, stream_ptr: Optional[int]) -> None:
-        self.check(self.lib.slam_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+        """Enqueue on this hipStream_t handle from now on (0 is HIP's null stream = torch's default stream);
+        None goes back to the ctx's own stream."""
+        if stream_ptr is None:
+            self.check(self.lib.slam_use_own_stream(self.h))
+        else:
+            self.check(self.lib.slam_set_stream(self.h, C.c_void_p(int(stream_ptr))))
 
     def sync(self) -> None:
         self.check(self.lib.slam_sync(self.h))

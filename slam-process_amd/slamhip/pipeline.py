@@ -41,7 +41,8 @@ class FramePipeline:
                  mapping: Optional[Dict[int, float]] = None, lut: Optional[np.ndarray] = None,
                  blur_sigma: float = 1.0, use_log: bool = False, vmin: Optional[float] = None,
                  vmax: Optional[float] = None, cycle: int = ops.CYCLE, tol: int = ops.TOL,
-                 mod_base: int = ops.MOD_BASE, src_is_bytes: bool = False, n_tile_slots: Optional[int] = None):
+                 mod_base: int = ops.MOD_BASE, src_is_bytes: bool = False, n_tile_slots: Optional[int] = None,
+                 n_compact_slots: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("FramePipeline needs a GPU (the HIP path has no CPU fallback)")
         self.dev = torch.device("cuda", device)
@@ -71,7 +72,11 @@ class FramePipeline:
         self.k_bs = torch.empty(F * rc, dtype=u8, device=d)
         self.k_rss = torch.empty(F * rc, dtype=u32, device=d)
         self.k_clk = torch.empty(F * rc, dtype=u32, device=d)
-        self.stats = torch.zeros(F * _lib.STAT_WORDS, dtype=u32, device=d)
+        # What a tile is painted from (cell colours, pixel -> cell maps) and the frame's stats words live in one
+        # flat buffer per slot, so a rank can ship a batch's results in one 20 KB-per-frame message.
+        self.compact_layout = compact_layout(F, self.tile_w, self.tile_h)
+        self.compact = torch.zeros((int(n_compact_slots), self.compact_layout["bytes"]), dtype=u8, device=d)
+        self.compact_slot = 0
         self.matrix = torch.empty(F * self.n_axis * self.n_axis, dtype=torch.float64, device=d)
         self.blurred = torch.empty(F * self.n_axis * self.n_axis, dtype=torch.float64, device=d)
         self.n_tile_slots = int(n_tile_slots or F)
@@ -100,7 +105,7 @@ class FramePipeline:
         bt.kept_ue_dev, bt.kept_bs_dev = self.k_ue.data_ptr(), self.k_bs.data_ptr()
         bt.kept_rss_dev, bt.kept_clk_dev = self.k_rss.data_ptr(), self.k_clk.data_ptr()
         bt.kept_cnt_dev = self.kept_cnt.data_ptr()
-        bt.stats_dev = self.stats.data_ptr()
+        self._point_compact(bt, 0)
         bt.matrix_dev = self.matrix.data_ptr()
         bt.blurred_dev = self.blurred.data_ptr()
         bt.tile_dev = self.tiles.data_ptr()
@@ -111,6 +116,18 @@ class FramePipeline:
         # reserve the library workspace once, so steady-state calls allocate nothing
         bt.text_dev = self.flag.data_ptr()          # any non-null pointer: only the shape matters here
         self.ctx.check(self.ctx.lib.slam_reserve_workspace(self.ctx.h, C.byref(bt)))
+
+    def _point_compact(self, bt, slot: int) -> None:
+        base, lay = self.compact[slot].data_ptr(), self.compact_layout
+        bt.cells_dev, bt.colmap_dev = base + lay["cells"], base + lay["colmap"]
+        bt.rowmap_dev, bt.stats_dev = base + lay["rowmap"], base + lay["stats"]
+        self.compact_slot = slot
+
+    @property
+    def stats(self) -> torch.Tensor:
+        """int32 view of the current slot's stats words [F * STAT_WORDS]."""
+        lay = self.compact_layout
+        return self.compact[self.compact_slot][lay["stats"]:lay["stats"] + self.F * _lib.STAT_WORDS * 4].view(torch.int32)
 
     def set_uniform_layout(self, n_frames: int, frame_stride: int, text_len: int) -> None:
         """Frames of equal length laid out at a fixed stride in the text buffer."""
@@ -128,9 +145,12 @@ class FramePipeline:
         self.len[:n] = torch.tensor(list(lengths), dtype=torch.int64, device=self.dev).to(torch.int32)
         self.bt.n_frames = n
 
-    def run(self, text: torch.Tensor, text_base_offset: int = 0, stages: int = STAGE_ALL, tile_slot: int = 0) -> None:
+    def run(self, text: torch.Tensor, text_base_offset: int = 0, stages: int = STAGE_ALL, tile_slot: int = 0,
+            compact_slot: Optional[int] = None) -> None:
         """Enqueue one batch on torch's current stream (no synchronisation)."""
         self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        if compact_slot is not None and compact_slot != self.compact_slot:
+            self._point_compact(self.bt, int(compact_slot))
         self._text_keep = text
         self.bt.text_dev = text.data_ptr() + int(text_base_offset)
         self.bt.tile_dev = self.tiles.data_ptr() + int(tile_slot) * self.tile_h * self.tile_w * 4
@@ -187,6 +207,33 @@ class FramePipeline:
     def frame_tile(self, f: int, tile_slot: int = 0) -> np.ndarray:
         torch.cuda.synchronize(self.dev)
         return self.tiles[tile_slot + f].cpu().numpy()
+
+
+def compact_layout(F: int, W: int, H: int) -> Dict[str, int]:
+    """Byte offsets of the per-batch result buffer: cells [F*16384] | colmap [F*2W] | rowmap [F*2H] | stats [F*64]."""
+    al = lambda x: (x + 255) // 256 * 256
+    cells = 0
+    colmap = al(cells + F * 4096 * 4)
+    rowmap = al(colmap + F * W * 2)
+    stats = al(rowmap + F * H * 2)
+    return dict(cells=cells, colmap=colmap, rowmap=rowmap, stats=stats, bytes=al(stats + F * _lib.STAT_WORDS * 4))
+
+
+def expand_compact(buf: torch.Tensor, F: int, W: int, H: int, out: Optional[torch.Tensor] = None,
+                   device: Optional[int] = None) -> torch.Tensor:
+    """Paint the F tiles a compact result buffer (FramePipeline.compact[slot], possibly received from another rank)
+    describes: [F, H, W, 4] uint8, bit-identical to the tiles the producing pipeline rendered."""
+    dev = buf.device
+    c = _lib.ctx(dev.index if device is None else device)
+    lay = compact_layout(F, W, H)
+    if out is None:
+        out = torch.empty((F, H, W, 4), dtype=torch.uint8, device=dev)
+    c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    base = buf.data_ptr()
+    c.check(c.lib.slam_raster_dev(c.h, C.c_void_p(base + lay["cells"]), C.c_void_p(base + lay["colmap"]),
+                                  C.c_void_p(base + lay["rowmap"]), C.c_void_p(base + lay["stats"]), int(F), int(W),
+                                  int(H), C.c_void_p(out.data_ptr())))
+    return out
 
 
 def synth_frames(n_frames: int, B: int, N: int, first_frame: int = 0, seed: int = 20260126, device: int = 0,

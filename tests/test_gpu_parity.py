@@ -328,6 +328,10 @@ def test_batched_pipeline_against_oracle(mapping, lut, shape, two_pass, monkeypa
         r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=128)
         assert (lo, hi) == (r["vmin"], r["vmax"])
         assert np.array_equal(pipe.frame_tile(f), r["tile"])
+    # the compact per-batch result buffer repaints to the same tiles (what a collecting rank does)
+    from slamhip.pipeline import expand_compact
+    again = expand_compact(pipe.compact[pipe.compact_slot].clone(), F, 256, 128)
+    assert torch.equal(again, pipe.tiles[:F])
 
 
 def _hostile_streams():
