@@ -580,6 +580,13 @@ __device__ __forceinline__ int32_t round_to_beam(uint32_t q1, uint32_t r, uint32
     const uint32_t cyc = (uint32_t)prm.cycle;
     const int32_t Q = (int32_t)(q1 - qb);
     const int32_t x = (int32_t)r - (int32_t)vw;
+    if (prm.small_tol) {
+        // 0 <= 2*tol < cycle and the circular distance is within tol: |x| <= tol, or the pair wraps around the
+        // cycle (|x| >= cycle - tol > cycle / 2) and k moves one step; an exact half never occurs
+        const uint32_t ax = (uint32_t)(x < 0 ? -x : x);
+        const int32_t k = Q + (ax > (uint32_t)prm.tol ? (x > 0 ? 1 : -1) : 0);
+        return ((int32_t)bs_b + k) & (prm.mod_base - 1);
+    }
     const uint32_t ax2 = 2u * (uint32_t)(x < 0 ? -x : x);
     int32_t k;
     if (ax2 < cyc) k = Q;
@@ -1064,6 +1071,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     TC *corr = reinterpret_cast<TC *>(ws.corr);
     const int og = (prm.one_group || prm.explicit_baselines ? 1 : 0) | (prm.explicit_baselines ? 2 : 0);
     const int keep_bl = prm.explicit_baselines ? 1 : 0;
+    correct_params prm_k = prm;
+    prm_k.small_tol = prm.tol >= 0 && 2 * (int64_t)prm.tol < (int64_t)prm.cycle && (prm.mod_base & (prm.mod_base - 1)) == 0;
     if (in.slot_cnt && in.bits.rmask && out.slot_cnt && !og) {
         // bits per framing tile (left by the framing pass, completed here) -> scan over tiles -> tables -> fused
         // correction; the per-block summarize / groups kernels are not needed
@@ -1083,7 +1092,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), w2, in.row_cap, prm, stats,
                     in.bits, WAVE_SORT_MAX);
         SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
-                    rt_max, ws.rt_nbound, w2, prm, out, stats);
+                    rt_max, ws.rt_nbound, w2, prm_k, out, stats);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
@@ -1101,11 +1110,11 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
         SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
-                    rt_max, ws.rt_nbound, ws, prm, out, stats);
+                    rt_max, ws.rt_nbound, ws, prm_k, out, stats);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
-                corr, prm, ws.rt_nkept, stats);
+                corr, prm_k, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,
                 (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ROWS_PER_BLOCK);
     if (out.ue) {

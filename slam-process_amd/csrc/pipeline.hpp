@@ -126,6 +126,7 @@ struct correct_params {
     uint32_t div_m = 0, div_s1 = 0, div_s2 = 0;   // division by cycle as a multiply-high (set_cycle)
     uint32_t bias = 0;                            // multiple of cycle >= 2^30 added to clocks before dividing
     void set_cycle(int32_t c);
+    int small_tol = 0;          // set by correct_rows: 0 <= 2*tol < cycle and mod_base a power of two
     int one_group = 0;          // 1: the whole table is one group (UE wraps ignored)
     int explicit_baselines = 0; // 1: baselines preloaded into bl_clk/bl_bs, count in stats BASELINES (implies one_group)
 };
