@@ -65,6 +65,12 @@ int slam_parse_records(slam_ctx *ctx, const uint8_t *bytes, size_t n,
                        uint8_t *flag, uint8_t *ue, uint8_t *bs, uint32_t *rss, uint32_t *clk,
                        size_t cap, size_t *n_valid, size_t *n_discarded);
 
+/* Diagnostics of a2: the byte indices at which _parse_groups discards a group, in scan order — one per "丢弃组"
+ * log line (serial_hex_to_excel_v3.py:53-58 truncated tail, :62-87 failed tag checks).  The reason and the hex dump
+ * of each line follow from the bytes at that index.  n_rejects equals the `discarded` counter; cap >= it. */
+int slam_parse_rejects(slam_ctx *ctx, const uint8_t *bytes, size_t n,
+                       uint32_t *pos_out, size_t cap, size_t *n_rejects);
+
 /* a1+a2 fused: text straight to records (the text is never materialised as bytes when it has
  * the capture format "XX XX XX ..." with an optional leading "« "). */
 int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text,

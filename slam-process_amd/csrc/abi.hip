@@ -392,6 +392,39 @@ extern "C" int slam_parse_records(slam_ctx *ctx, const uint8_t *bytes, size_t n,
     return parse_common(ctx, SRC_RAW, bytes, n, flag, ue, bs, rss, clk, cap, n_valid, n_discarded);
 }
 
+extern "C" int slam_parse_rejects(slam_ctx *ctx, const uint8_t *bytes, size_t n, uint32_t *pos_out, size_t cap,
+                                  size_t *n_rejects)
+{
+    REQUIRE_CTX(ctx);
+    if ((!bytes && n) || !n_rejects) return slam_fail(ctx, SLAM_E_INVALID, "slam_parse_rejects: null argument");
+    if (n > 0xFFFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "input larger than 4 GiB");
+    *n_rejects = 0;
+    if (n == 0) return SLAM_OK;
+    const uint32_t row_cap = round16(n / 11 + 16);
+    const uint32_t nt_max = frame_tiles_for(SRC_RAW, (uint32_t)n);
+    ws_plan p;
+    size_t off[16];
+    one_frame_plan(p, n, row_cap, nt_max, off);
+    const size_t o_pos = p.add((n + 16) * sizeof(uint32_t));          // every byte could be a discarded flag byte
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    one_frame fr;
+    one_frame_bind(fr, ctx->ws, off, row_cap, nt_max);
+    SLAM_TRY(h2d(ctx, fr.src, bytes, n));
+    SLAM_TRY(set_one_frame_desc(ctx, fr, (uint32_t)n));
+    frame_src fs{fr.src, fr.off, fr.len, nullptr, 0, nullptr};
+    SLAM_TRY(frame_decode(ctx, SRC_RAW, fs, 1, (uint32_t)n, fr.fws, nt_max, fr.rows, fr.stats));
+    uint32_t *pos_dev = (uint32_t *)(ctx->ws + o_pos);
+    SLAM_TRY(frame_rejects(ctx, SRC_RAW, fs, 1, fr.fws, nt_max, pos_dev, (uint32_t)(n + 16)));
+    uint32_t st[SLAM_STAT_WORDS];
+    SLAM_TRY(read_stats(ctx, fr.stats, st));
+    *n_rejects = st[SLAM_STAT_DISCARDED];
+    if (*n_rejects > cap || (*n_rejects && !pos_out))
+        return slam_fail(ctx, SLAM_E_CAPACITY, "slam_parse_rejects: need room for %zu positions, have %zu", *n_rejects, cap);
+    SLAM_TRY(d2h(ctx, pos_out, pos_dev, *n_rejects * sizeof(uint32_t)));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
 extern "C" int slam_parse_text(slam_ctx *ctx, const uint8_t *text, size_t n_text, uint8_t *flag, uint8_t *ue,
                                uint8_t *bs, uint32_t *rss, uint32_t *clk, size_t cap, size_t *n_valid,
                                size_t *n_discarded)
@@ -596,7 +629,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[5], cw[16], rw[5], tc, tb[3];
+    size_t fw[6], cw[16], rw[5], tc, tb[3];
     uint32_t nt_max, st_max, bl_cap;
     size_t total;
 };

@@ -457,7 +457,8 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
 // ---- per-frame scan over tiles --------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_frame_scan(const uint32_t *summ, uint32_t nt_max,
                                                       uint8_t *tile_entry, uint32_t *tile_off, uint32_t *stats,
-                                                      int gated, uint32_t *slot_cnt, uint32_t slot_stride)
+                                                      int gated, uint32_t *slot_cnt, uint32_t slot_stride,
+                                                      uint32_t *tile_off_d)
 {
     __shared__ uint8_t ent[1025];
     __shared__ uint32_t sh[17];
@@ -501,8 +502,11 @@ __global__ __launch_bounds__(1024) void k_frame_scan(const uint32_t *summ, uint3
         }
         uint32_t totv, totd;
         uint32_t ex = block_excl_scan(v, sh, &totv);
-        block_excl_scan(d, sh, &totd);
-        if (have) tile_off[(size_t)f * nt_max + t] = carry_v + ex;
+        uint32_t exd = block_excl_scan(d, sh, &totd);
+        if (have) {
+            tile_off[(size_t)f * nt_max + t] = carry_v + ex;
+            tile_off_d[(size_t)f * nt_max + t] = carry_d + exd;
+        }
         uint32_t cnt = nt - seg < 1024 ? nt - seg : 1024;
         carry_e = ent[cnt];
         carry_v += totv;
@@ -570,6 +574,47 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
         o++;
     }
     wave_lds_sync();
+    }
+}
+
+// ---- diagnostics: positions of the flag bytes the scan discards -------------------------------------------
+// Same walk as pass 2, emitting instead of records the data-byte index of every discarded flag byte, in scan
+// order: the positions `_parse_groups` logs one "丢弃组" line for (serial_hex_to_excel_v3.py:53-58, :62-87).
+// The reason and the hex dump of a line follow from the bytes at that index.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_frame_rejects(frame_src src, uint32_t nt_max, const uint8_t *tile_entry,
+                                                        const uint32_t *tile_off_d, uint32_t *pos_out, uint32_t pos_cap)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][FRAME_TILE_DW];
+    const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    const src_view sv = resolve_src<MODE>(src, f);
+    const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
+    uint32_t bad = 0;
+    uint32_t *tile = lds[wv];
+    for (uint32_t j = 0; j < FRAME_TPW; j++) {
+        const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+        if (t >= nt) break;
+        const uint32_t tile_start = t * FRAME_TILE;
+        fill_tile<MODE, false>(tile, sv, tile_start, &bad, nullptr);
+        wave_lds_sync();
+        const run_masks m = make_masks(tile, (int64_t)sv.nb - (int64_t)tile_start - (int64_t)lane * FRAME_RUN);
+        const uint64_t exits = closure(0x7FFull, m) >> FRAME_RUN;
+        const uint32_t x = __popcll(exits) == 1 ? (uint32_t)__builtin_ctzll(exits) : UNK;
+        uint32_t ex;
+        const uint32_t entry = resolve_entries(m, x, tile_entry[(size_t)f * nt_max + t], &ex);
+        const uint64_t v = closure(1ull << entry, m);
+        uint64_t rej = v & m.rej;
+        const uint64_t tl = v & m.tail;
+        if (tl) rej |= tl & (~tl + 1);                    // the scan ends at the first tail position it visits
+        const uint32_t cnt = __popcll(rej);
+        const uint32_t inc = wave_incl_scan(cnt);
+        size_t o = (size_t)f * pos_cap + tile_off_d[(size_t)f * nt_max + t] + (inc - cnt);
+        while (rej) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(rej);
+            rej &= rej - 1;
+            pos_out[o++] = tile_start + lane * FRAME_RUN + p;
+        }
+        wave_lds_sync();
     }
 }
 
@@ -783,6 +828,25 @@ uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
     return nt ? nt : 1;
 }
 
+int frame_rejects(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, const frame_ws &ws, uint32_t nt_max,
+                  uint32_t *pos_out, uint32_t pos_cap)
+{
+    if (F == 0) return SLAM_OK;
+    dim3 grid((nt_max + 4 * FRAME_TPW - 1) / (4 * FRAME_TPW), F), block(256);
+    frame_src src = src_in;
+    src.dec = ws.dec;
+    src.dec_stride = ws.dec_stride;
+    src.fdesc = ws.fdesc;
+    if (mode == SRC_TEXT3) {
+        SLAM_LAUNCH(ctx, "frame_rejects", (k_frame_rejects<SRC_DEC>), grid, block, src, nt_max, ws.tile_entry,
+                    ws.tile_off_d, pos_out, pos_cap);
+    } else {
+        SLAM_LAUNCH(ctx, "frame_rejects", (k_frame_rejects<SRC_RAW>), grid, block, src, nt_max, ws.tile_entry,
+                    ws.tile_off_d, pos_out, pos_cap);
+    }
+    return SLAM_OK;
+}
+
 uint32_t slot_tiles_for(int mode, uint32_t max_src_len)
 {
     uint64_t nb = mode == SRC_TEXT3 ? ((uint64_t)max_src_len + 1) / 3 : max_src_len;
@@ -795,18 +859,20 @@ extern "C" uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes)
     return slot_tiles_for(src_is_bytes ? SRC_RAW : SRC_TEXT3, max_text_len);
 }
 
-void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[5])
+void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[6])
 {
     off[4] = p.add((size_t)F * sizeof(frame_desc));
+    off[5] = p.add((size_t)F * nt_max * sizeof(uint32_t));
     off[0] = p.add((size_t)F * nt_max * FRAME_SUMM_WORDS * sizeof(uint32_t));
     off[1] = p.add((size_t)F * nt_max);
     off[2] = p.add((size_t)F * nt_max * sizeof(uint32_t));
     off[3] = p.add((size_t)F * dec_stride_for(nt_max));
 }
 
-void frame_ws::bind(uint8_t *b, const size_t off[5], uint32_t nt_max)
+void frame_ws::bind(uint8_t *b, const size_t off[6], uint32_t nt_max)
 {
     fdesc = (frame_desc *)(b + off[4]);
+    tile_off_d = (uint32_t *)(b + off[5]);
     summ = (uint32_t *)(b + off[0]);
     tile_entry = b + off[1];
     tile_off = (uint32_t *)(b + off[2]);
@@ -854,7 +920,7 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, u
                     (uint8_t *)nullptr, (uint64_t)0, slotted);
     }
     SLAM_LAUNCH(ctx, "frame_scan", k_frame_scan, dim3(F), dim3(1024), ws.summ, nt_max, ws.tile_entry,
-                ws.tile_off, stats, slotted, out.slot_cnt, out.slot_stride);
+                ws.tile_off, stats, slotted, out.slot_cnt, out.slot_stride, ws.tile_off_d);
     const uint32_t *gate = slotted ? stats : nullptr;
     if (mode == SRC_TEXT3) {
         SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_DEC>), grid, block, src, nt_max, ws.tile_entry,

@@ -33,7 +33,8 @@ struct frame_src {
 struct frame_ws {               // device scratch of the framing stage
     uint32_t *summ;             // [F * nt_max * 11]
     uint8_t *tile_entry;        // [F * nt_max]
-    uint32_t *tile_off;         // [F * nt_max]
+    uint32_t *tile_off;         // [F * nt_max] records before each tile
+    uint32_t *tile_off_d;       // [F * nt_max] discards before each tile
     uint8_t *dec;               // [F * dec_stride] decoded data bytes of text frames
     uint64_t dec_stride;
     static uint64_t dec_stride_for(uint32_t nt_max) { return (uint64_t)nt_max * FRAME_TILE + 256; }
@@ -78,6 +79,10 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint
                  const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats);
 uint32_t frame_tiles_for(int mode, uint32_t max_src_len);
 uint32_t slot_tiles_for(int mode, uint32_t max_src_len);
+// After a dense (two-pass) frame_decode of the same source: data-byte indices of the discarded flag bytes, in scan
+// order, frame f at f*pos_cap (stats DISCARDED of them).
+int frame_rejects(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, const frame_ws &ws, uint32_t nt_max,
+                  uint32_t *pos_out, uint32_t pos_cap);
 
 // ---- correction ----------------------------------------------------------------------------------
 constexpr int ROWS_PER_BLOCK = SLAM_KEPT_BLOCK;  // 256 threads x 4 rows

@@ -7,8 +7,9 @@ libslamhip.so.  There is no CPU implementation behind these functions: without t
 GPU they raise.
 
 Differences a caller can see: the workbook is written with the standard library (no openpyxl
-needed), and the per-token / per-reject log lines are summarised (counts and the first rejects'
-positions) instead of one line each.
+needed), and the per-token lines of _read_bytes are summarised.  The per-reject lines of
+_parse_groups are reproduced one by one: the device returns where the scan discarded a group, the
+reason and the hex dump of each line are read off the bytes at that index.
 """
 from __future__ import annotations
 
@@ -52,8 +53,35 @@ def _parse_groups(bytes_list: List[int], logger: logging.Logger) -> Tuple[List[T
     rows = list(zip(cols["flag"].tolist(), cols["ue"].tolist(), cols["bs"].tolist(),
                     cols["rss"].tolist(), cols["clk"].tolist()))
     if discarded:
-        logger.error("丢弃组数=%d (flag bytes whose followers fail the tag checks, or a truncated tail)", discarded)
+        for line in reject_lines(bytes_list, ops.parse_rejects(bytes_list, discarded)):
+            logger.error(line)
     return rows, valid, discarded
+
+
+def reject_lines(bytes_list, positions) -> List[str]:
+    """The "丢弃组" message the reference logs at each discard position (:55-57, :64, :69, :77, :85)."""
+    n = len(bytes_list)
+    out = []
+    for i in (int(p) for p in positions):
+        if i + 11 > n:
+            out.append(f"丢弃组，起始索引{i}，原因：字节数量不足11个，剩余{n - i}字节，数据={_fmt_bytes(list(bytes_list[i:n]))}")
+            continue
+        grp = [int(v) for v in bytes_list[i:i + 11]]
+        ue, bs = grp[1], grp[2]
+        data = _fmt_bytes(grp)
+        if _top2(ue) != 0b00:
+            out.append(f"丢弃组，起始索引{i}，原因：UE_Beam位[7:6]不为00，UE={_to_hex(ue)}，数据={data}")
+            continue
+        if _top2(bs) != 0b11:
+            out.append(f"丢弃组，起始索引{i}，原因：BS_Beam位[7:6]不为11，BS={_to_hex(bs)}，数据={data}")
+            continue
+        bad_clk = next((b for b in grp[3:8] if _top2(b) != 0b01), None)
+        if bad_clk is not None:
+            out.append(f"丢弃组，起始索引{i}，原因：CLK字节位[7:6]不为01，BAD={_to_hex(bad_clk)}，数据={data}")
+            continue
+        bad_rss = next((b for b in grp[8:11] if _top2(b) != 0b10), None)
+        out.append(f"丢弃组，起始索引{i}，原因：RSS字节位[7:6]不为10，BAD={_to_hex(bad_rss if bad_rss is not None else 0)}，数据={data}")
+    return out
 
 
 def parse_file(path: Path, logger: logging.Logger):

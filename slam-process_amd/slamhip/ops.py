@@ -55,6 +55,17 @@ def parse_records(data, device: int = 0):
     return _parse("slam_parse_records", b, len(b) // 11 + 2, device)
 
 
+def parse_rejects(data, n_discarded: Optional[int] = None, device: int = 0) -> np.ndarray:
+    """Byte indices at which _parse_groups discards a group, in scan order (uint32 array)."""
+    b = _u8(data)
+    c = _lib.ctx(device)
+    cap = len(b) + 1 if n_discarded is None else int(n_discarded) + 1
+    pos = np.empty(cap, np.uint32)
+    n = C.c_size_t()
+    c.check(c.lib.slam_parse_rejects(c.h, _lib.ptr(b), len(b), _lib.ptr(pos), cap, C.byref(n)))
+    return pos[: n.value].copy()
+
+
 def parse_text(text, device: int = 0):
     """_read_bytes + _parse_groups fused: raw file bytes -> (columns dict, valid, discarded)."""
     t = _u8(text)

@@ -395,3 +395,37 @@ def test_batched_bytes_hostile_streams(mapping, lut, two_pass, split_stages, mon
             kept = pipe.frame_kept(f, st)
             for k in kept_o:
                 assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
+
+
+def test_reject_positions_and_log_lines(golden_dir, ops):
+    """slam_parse_rejects gives the scan's discard positions (oracle) and the drop-in _parse_groups logs the
+    reference's lines one by one (golden lines captured from the reference's logger)."""
+    import json
+    import logging
+    import serial_hex_to_excel_v3 as drop
+    doc = json.load(open(os.path.join(golden_dir, "reject_lines.json"), encoding="utf-8"))
+    streams = {k: np.array(e["bytes"], np.uint8) for k, e in doc.items()}
+    for i, sb in enumerate(_hostile_streams()):
+        streams[f"hostile_{i}"] = np.frombuffer(sb, np.uint8)
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.DEBUG)
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(record.getMessage())
+
+    lg = logging.getLogger("test_rejects")
+    lg.setLevel(logging.DEBUG)
+    lg.propagate = False
+    for name, by in streams.items():
+        _, v, d, pos_o, _ = O.parse_groups(by, want_rejects=True)
+        pos = ops.parse_rejects(by)
+        assert np.array_equal(pos.astype(np.int64), np.asarray(pos_o, np.int64)), name
+        if name in doc:
+            cap = Capture()
+            lg.handlers[:] = [cap]
+            rows, v2, d2 = drop._parse_groups(by.tolist(), lg)
+            assert (v2, d2) == (doc[name]["valid"], doc[name]["discarded"]), name
+            assert cap.lines == doc[name]["lines"], name

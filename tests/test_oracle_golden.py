@@ -132,3 +132,23 @@ def test_pivot_rows_with_bad_or_unmapped_beams_are_dropped(mapping):
     mat, aod, aoa, s, c = O.pivot_mean(ue, bs, rss, mp)
     assert c.sum() == 3 and mat.shape == (2, 2)
     assert mat[1, 1] == 60.0 and mat[0, 0] == 10.0 and np.isnan(mat[0, 1])
+
+
+def test_reject_positions_and_log_lines_match_reference(golden_dir):
+    """Oracle discard positions + the drop-in module's line formatter reproduce the reference's per-reject log
+    lines (serial_hex_to_excel_v3.py:55-57, :64, :69, :77, :85) on every golden stream."""
+    import importlib.util
+    import json
+    from conftest import PKG
+    # under a private name: the reference's module of the same name is imported by other tests
+    spec = importlib.util.spec_from_file_location("dropin_serial_hex", os.path.join(PKG, "serial_hex_to_excel_v3.py"))
+    drop = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drop)
+    doc = json.load(open(os.path.join(golden_dir, "reject_lines.json"), encoding="utf-8"))
+    assert len(doc) >= 25
+    for name, e in doc.items():
+        by = np.array(e["bytes"], np.uint8)
+        rows, v, d, pos, reason = O.parse_groups(by, want_rejects=True)
+        assert (v, d) == (e["valid"], e["discarded"]), name
+        assert len(pos) == d
+        assert drop.reject_lines(by.tolist(), pos) == e["lines"], name
