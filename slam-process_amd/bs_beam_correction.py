@@ -128,6 +128,29 @@ def _write_table(path: str, df: pd.DataFrame) -> None:
     xlsx.write_table(path, list(df.columns), [df[c].tolist() for c in df.columns])
 
 
+def _log_groups(res, filtered: bool) -> None:
+    """The reference's per-group lines, in group order: a warning for a group without baselines
+    (:131-132, :191-192) and the summary its per-group function logs (:108-115, :171-177).  Row indices
+    are those of the default RangeIndex the reference's DataFrame has."""
+    gid = np.asarray(res["gid"], np.int64)
+    ng = int(res["n_groups"])
+    if ng == 0 or len(gid) == 0:
+        return
+    n_bl = np.bincount(np.asarray(res["baselines"][2], np.int64), minlength=ng)
+    first = np.searchsorted(gid, np.arange(ng), side="left")
+    last = np.searchsorted(gid, np.arange(ng), side="right") - 1
+    n_corr = np.bincount(gid[np.asarray(res["corrected"]) >= 0], minlength=ng)
+    for g in range(ng):
+        if n_bl[g] == 0:
+            logging.warning("组%d 未识别到基准值，已跳过组内所有预测行" if filtered else "组%d 未识别到基准值", g)
+        if filtered:
+            logging.info("过滤组索引范围[%s-%s] 基准数量=%d 输出修正数量=%d", str(first[g]), str(last[g]),
+                         int(n_bl[g]), int(n_corr[g]))
+        else:
+            logging.info("组索引范围[%s-%s] 基准数量=%d 修正数量=%d 总行数=%d", str(first[g]), str(last[g]),
+                         int(n_bl[g]), int(n_corr[g]), int(last[g] - first[g] + 1))
+
+
 def process_excel(input_path: str) -> None:
     """Adds Corrected_BS_Beam to every row and writes the workbook back in place (reference :119-138)."""
     df = _read_table(input_path)
@@ -135,13 +158,9 @@ def process_excel(input_path: str) -> None:
     df = _coerce_types(df)
     f, u, b, r, c = _columns(df)
     res = ops.correct(f, u, b, r, c, CYCLE, TOL, MOD_BASE)
-    gid = res["gid"]
-    n_bl = np.bincount(res["baselines"][2], minlength=res["n_groups"]) if res["n_groups"] else np.zeros(0, int)
-    for g in np.flatnonzero(n_bl == 0):
-        logging.warning("组%d 未识别到基准值", g)
+    _log_groups(res, filtered=False)
     corr = res["corrected"].astype(np.int64)
     df[OUT_COL] = np.where(corr >= 0, corr, np.asarray(b).astype(np.int64)).astype(np.float64)
-    _ = gid
     _write_table(input_path, df)
     logging.info("已写回修正文件: %s", input_path)
 
@@ -153,9 +172,7 @@ def process_excel_filtered(input_path: str, output_path: Optional[str] = None) -
     df = _coerce_types(df)
     f, u, b, r, c = _columns(df)
     res = ops.correct(f, u, b, r, c, CYCLE, TOL, MOD_BASE)
-    n_bl = np.bincount(res["baselines"][2], minlength=res["n_groups"]) if res["n_groups"] else np.zeros(0, int)
-    for g in np.flatnonzero(n_bl == 0):
-        logging.warning("组%d 未识别到基准值，已跳过组内所有预测行", g)
+    _log_groups(res, filtered=True)
     ku, kb, kr, kc = res["kept"]
     if len(ku) == 0:
         raise ValueError("未产生任何可修正数据行，输出为空")

@@ -212,3 +212,41 @@ def test_long_sweep_and_wide_frames_bit_exact(shape):
     assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
     r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=256)
     assert np.array_equal(pipe.frame_tile(0), r["tile"])
+
+
+def test_per_group_log_lines_follow_the_reference(tmp_path):
+    """process_excel_filtered / process_excel log, group by group, what the reference's loops log
+    (bs_beam_correction.py:125-134, :186-195); golden lines captured from the reference's own functions."""
+    import bs_beam_correction as B
+    import serial_hex_to_excel_v3 as S
+    from slamhip import xlsx
+    doc = json.load(open(os.path.join(GOLDEN, "group_log_lines.json"), encoding="utf-8"))
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.DEBUG)
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(f"{record.levelname} {record.getMessage()}")
+
+    root = logging.getLogger()
+    old_handlers, old_level = root.handlers[:], root.level
+    root.setLevel(logging.DEBUG)
+    try:
+        for name, e in doc.items():
+            cols = [list(c) for c in zip(*e["rows"])]
+            for key, fn in (("filtered", B.process_excel_filtered), ("inplace", B.process_excel)):
+                p = tmp_path / f"{name}_{key}.xlsx"
+                xlsx.write_table(str(p), S.HEADER, cols, sheet="Parsed")
+                cap = Capture()
+                root.handlers[:] = [cap]
+                try:
+                    fn(str(p))
+                except ValueError:
+                    pass                                   # a table with nothing to keep still logs its groups first
+                lines = [ln for ln in cap.lines if "已生成" not in ln and "已写回" not in ln]
+                assert lines == e[key], (name, key)
+    finally:
+        root.handlers[:] = old_handlers
+        root.setLevel(old_level)
