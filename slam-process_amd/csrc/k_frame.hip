@@ -27,6 +27,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "pipeline.hpp"
 
 namespace {
@@ -387,8 +389,10 @@ __global__ __launch_bounds__(256) void k_frame_summarize(frame_src src, uint32_t
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     uint32_t *tile = lds[wv];
     uint32_t bad = 0;
+    // grid-stride over groups of 4 * FRAME_TPW tiles: the gated launches use a small grid
+    for (uint32_t bx = blockIdx.x; bx * (4 * FRAME_TPW) < nt; bx += gridDim.x)
     for (uint32_t j = 0; j < FRAME_TPW; j++) {
-    const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+    const uint32_t t = (bx * FRAME_TPW + j) * 4 + wv;
     if (t >= nt) break;
     const uint32_t tile_start = t * FRAME_TILE;
     {
@@ -539,8 +543,9 @@ __global__ __launch_bounds__(256) void k_frame_emit(frame_src src, uint32_t nt_m
     const uint32_t nt = (sv.nb + FRAME_TILE - 1) / FRAME_TILE;
     uint32_t bad = 0;
     uint32_t *tile = lds[wv];
+    for (uint32_t bx = blockIdx.x; bx * (4 * FRAME_TPW) < nt; bx += gridDim.x)
     for (uint32_t j = 0; j < FRAME_TPW; j++) {
-    const uint32_t t = (blockIdx.x * FRAME_TPW + j) * 4 + wv;
+    const uint32_t t = (bx * FRAME_TPW + j) * 4 + wv;
     if (t >= nt) break;
     const uint32_t tile_start = t * FRAME_TILE;
     fill_tile<MODE, false>(tile, sv, tile_start, &bad, nullptr);
@@ -910,7 +915,9 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, u
             SLAM_LAUNCH(ctx, "frame_onepass", (k_frame_onepass<SRC_RAW>), g1, block, src, out, stats);
         }
     }
-    // two passes: every frame (dense layout) or only the frames the single pass flagged
+    // two passes: every frame (dense layout) or only the frames the single pass flagged (rare: a small grid whose
+    // workgroups stride over the tiles keeps the idle launches cheap)
+    if (slotted) grid.x = std::min<uint32_t>(grid.x, 8u);
     if (mode == SRC_TEXT3) {
         // pass 1 reads the text once, validates it and leaves the decoded bytes; pass 2 reads bytes
         SLAM_LAUNCH(ctx, "frame_summarize", (k_frame_summarize<SRC_TEXT3>), grid, block, src, nt_max, ws.summ, stats,
