@@ -40,11 +40,12 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--frames-per-step", type=int, default=100)
+    p.add_argument("--frames-per-step", type=int, default=800,
+                   help="frames per batch (one slam_process_frames_dev call); larger batches amortise launch tails")
     p.add_argument("--beams", type=int, default=256, help="rows (UE sweeps) per frame")
     p.add_argument("--samples", type=int, default=4096, help="records per row")
     p.add_argument("--tile", type=int, default=1024)
-    p.add_argument("--distinct-frames", type=int, default=1000, help="frames kept resident in HBM (ring)")
+    p.add_argument("--distinct-frames", type=int, default=1600, help="frames kept resident in HBM (ring)")
     p.add_argument("--gather", choices=("compact", "tiles", "none"), default="compact",
                    help="N>1: what every step sends to rank 0")
     p.add_argument("--no-gather", action="store_true", help="same as --gather none")

@@ -11,4 +11,4 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) "$root/gpurun_out/prof/ke
 cd "$root"
 tools/pmc_pass.sh fetch "FETCH_SIZE"
 tools/pmc_pass.sh write "WRITE_SIZE"
-python3 tools/pmc_traffic.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv 100 256 4096 gpurun_out/prof/pmc_traffic.json
+python3 tools/pmc_traffic.py gpurun_out/pmc/fetch_counter_collection.csv gpurun_out/pmc/write_counter_collection.csv 800 256 4096 gpurun_out/prof/pmc_traffic.json
