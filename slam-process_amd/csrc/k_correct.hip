@@ -893,24 +893,49 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) lo[k] += (uint32_t)__shfl((int)t_r, (int)lo[k], 64) < r1[k] ? 1u : 0u;
+                    if (prm.small_tol) {
+                        // 0 <= 2*tol < cycle: a neighbour qualifies only through its short way round, so the forward
+                        // distance to the successor and the backward distance to the predecessor (either may wrap past
+                        // the cycle's end, which moves k by one) are the residuals; no absolute values, no halves.
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        // all lanes take part in the permutes; rows of other groups drop the result
-                        const uint32_t is = lo[k] < nd ? lo[k] : 0, ip = lo[k] > 0 ? lo[k] - 1 : nd - 1;
-                        const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
-                        const uint32_t cyc = (uint32_t)prm.cycle;
-                        const uint32_t ds_ = vs > r1[k] ? vs - r1[k] : r1[k] - vs, dp_ = vp > r1[k] ? vp - r1[k] : r1[k] - vp;
-                        const uint32_t rs_ = min(ds_, cyc - ds_), rp_ = min(dp_, cyc - dp_);
-                        bool pred = rp_ < rs_;
-                        if (__any(rp_ == rs_)) {                                     // ties: the earlier baseline (rare)
-                            const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
-                            pred = pred || (rp_ == rs_ && xp_ < xs_);
+                        for (int k = 0; k < 4; k++) {
+                            const bool wrap_s = lo[k] >= nd, wrap_p = lo[k] == 0;
+                            const uint32_t is = wrap_s ? 0u : lo[k], ip = wrap_p ? nd - 1 : lo[k] - 1;
+                            const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
+                            const uint32_t cyc = (uint32_t)prm.cycle;
+                            const uint32_t rs_ = vs + (wrap_s ? cyc : 0u) - r1[k], rp_ = r1[k] + (wrap_p ? cyc : 0u) - vp;
+                            bool pred = rp_ < rs_;
+                            if (__any(rp_ == rs_)) {                                 // ties: the earlier baseline (rare)
+                                const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
+                                pred = pred || (rp_ == rs_ && xp_ < xs_);
+                            }
+                            const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_;
+                            const int32_t adj = pred ? (wrap_p ? -1 : 0) : (wrap_s ? 1 : 0);
+                            const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
+                            if (fl[k] == 1 || gi[k] != gg || resid > (uint32_t)prm.tol) continue;
+                            res[k] = (int32_t)((wb + (q1[k] - wq) + (uint32_t)adj) & (uint32_t)(prm.mod_base - 1));
+                            keep |= 1u << k;
                         }
-                        const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_, vw = pred ? vp : vs;
-                        const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
-                        if (fl[k] == 1 || gi[k] != gg || (int64_t)resid > (int64_t)prm.tol) continue;
-                        res[k] = round_to_beam(q1[k], r1[k], wq, vw, wb, prm);
-                        keep |= 1u << k;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            // all lanes take part in the permutes; rows of other groups drop the result
+                            const uint32_t is = lo[k] < nd ? lo[k] : 0, ip = lo[k] > 0 ? lo[k] - 1 : nd - 1;
+                            const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
+                            const uint32_t cyc = (uint32_t)prm.cycle;
+                            const uint32_t ds_ = vs > r1[k] ? vs - r1[k] : r1[k] - vs, dp_ = vp > r1[k] ? vp - r1[k] : r1[k] - vp;
+                            const uint32_t rs_ = min(ds_, cyc - ds_), rp_ = min(dp_, cyc - dp_);
+                            bool pred = rp_ < rs_;
+                            if (__any(rp_ == rs_)) {                                     // ties: the earlier baseline (rare)
+                                const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
+                                pred = pred || (rp_ == rs_ && xp_ < xs_);
+                            }
+                            const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_, vw = pred ? vp : vs;
+                            const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
+                            if (fl[k] == 1 || gi[k] != gg || (int64_t)resid > (int64_t)prm.tol) continue;
+                            res[k] = round_to_beam(q1[k], r1[k], wq, vw, wb, prm);
+                            keep |= 1u << k;
+                        }
                     }
                 } else if (nd < TAB_CAP) {
                     if (in_lds_group != gg) {                       // consecutive blocks mostly stay in one group
