@@ -429,3 +429,84 @@ def test_reject_positions_and_log_lines(golden_dir, ops):
             rows, v2, d2 = drop._parse_groups(by.tolist(), lg)
             assert (v2, d2) == (doc[name]["valid"], doc[name]["discarded"]), name
             assert cap.lines == doc[name]["lines"], name
+
+
+def _wrap_stream(cycle: int, seed: int, groups: int = 6, rows_per_group: int = 700, n_baselines: int = 0) -> bytes:
+    """Records whose baseline phases sit at both ends of the cycle and in the middle, with rows on both sides of
+    every baseline (including across the wrap) at distances around the usual tolerances, and exact ties."""
+    rng = np.random.default_rng(seed)
+    rec = lambda fl, ue, bs, clk, rss: bytes([0xCC if fl else 0x33, ue & 63, 0xC0 | (bs & 63)] +
+                                             [0x40 | ((clk >> (6 * j)) & 63) for j in range(5)] +
+                                             [0x80 | ((rss >> (6 * j)) & 63) for j in range(3)])
+    out = bytearray()
+    phases = [0, 3, cycle - 1, cycle - 4, cycle // 2, cycle // 2 + 7, 1 + cycle // 3]
+    for g in range(groups):
+        nb = n_baselines or int(rng.integers(1, 60))       # baselines of the group
+        t = 0
+        for i in range(rows_per_group):
+            ue = min(63, i * 64 // rows_per_group)         # rising inside a group, drops at the next one
+            t += int(rng.integers(1, 4))
+            ph = int(phases[int(rng.integers(0, len(phases)))]) if g % 2 else int(rng.integers(0, cycle))
+            off = int(rng.choice([0, 1, -1, 499, 500, 501, -499, -500, -501, 250, -250, cycle // 2, 7]))
+            clk = (t * cycle + ph + off) % (1 << 30)
+            rss = int(rng.integers(15000, 90000))
+            if i % max(2, rows_per_group // nb) == 1:      # baseline: FLAG 0 -> 1 with the same RSS
+                prev_clk = (t * cycle + ph) % (1 << 30)
+                out += rec(0, ue, int(rng.integers(0, 64)), prev_clk, rss)
+                out += rec(1, ue, int(rng.integers(0, 64)), clk, rss)
+            else:
+                out += rec(0, ue, int(rng.integers(0, 64)), clk, rss)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("cycle,tol", [(61000, 500), (1000, 499), (1000, 500), (1000, 700), (977, 0), (64, 31)])
+def test_batched_correction_wraps_and_tolerances(mapping, lut, cycle, tol):
+    """Baseline phases at the ends of the cycle, rows across the wrap, ties, tolerances below / at / above half a
+    cycle: the batched correction (register-resident tables) against the oracle."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    streams = [_wrap_stream(cycle, s) for s in (1, 2, 3)]
+    offs, lens, blob = [], [], bytearray()
+    for sbytes in streams:
+        while len(blob) % 16:
+            blob.append(0xEE)
+        offs.append(len(blob)); lens.append(len(sbytes)); blob += sbytes
+    blob += b"\xEE" * 64
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True,
+                         cycle=cycle, tol=tol)
+    pipe.set_layout(offs, lens)
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    for f, sbytes in enumerate(streams):
+        rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+        assert (int(st[f, 2]), int(st[f, 3])) == (v, d)
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"],
+                                            cycle=cycle, tol=tol)
+        assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), f
+        assert ng > 1 and nb > 5 and len(kept_o["ue"]) > 50
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
+
+
+@pytest.mark.parametrize("n_baselines", [300, 1500, 2600])
+def test_batched_correction_large_groups(mapping, lut, n_baselines):
+    """Groups with more baselines than a wave holds: LDS tables (<= 1023 phases), tables searched in global memory,
+    the block bitonic sort (<= 2048 baselines) and the rank sort above it."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    cycle, tol = 61000, 500
+    sbytes = _wrap_stream(cycle, 11, groups=2, rows_per_group=3 * n_baselines, n_baselines=n_baselines)
+    text = torch.from_numpy(np.frombuffer(sbytes + b"\xEE" * 64, np.uint8).copy()).cuda()
+    pipe = FramePipeline(1, len(sbytes), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
+    pipe.set_layout([0], [len(sbytes)])
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+    kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+    assert nb >= 2 * n_baselines - 4
+    assert (int(st[0, 2]), int(st[0, 4]), int(st[0, 5]), int(st[0, 6])) == (v, ng, nb, len(kept_o["ue"]))
+    kept = pipe.frame_kept(0, st)
+    for k in kept_o:
+        assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
