@@ -134,7 +134,7 @@ int slam_render(slam_ctx *ctx, const double *mat, int h, int w,
  * All *_dev pointers are device pointers; optional outputs may be NULL. */
 typedef struct slam_batch {
     /* inputs */
-    const uint8_t *text_dev;      /* all frames' text                                           */
+    const uint8_t *text_dev;      /* all frames' text; readable up to 32 bytes past the last frame */
     const uint64_t *text_off_dev; /* [F] byte offset of each frame's text                        */
     const uint32_t *text_len_dev; /* [F] text bytes of each frame                                */
     uint32_t n_frames;            /* F                                                            */
