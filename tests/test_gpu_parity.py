@@ -510,3 +510,49 @@ def test_batched_correction_large_groups(mapping, lut, n_baselines):
     kept = pipe.frame_kept(0, st)
     for k in kept_o:
         assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+
+
+def test_batched_correction_with_record_free_gaps(mapping, lut):
+    """Stretches without records (longer than the look-behind run) before group starts, baselines and ordinary rows:
+    the tiles after them cannot take the previous row from their look-behind run and get their bits from the row
+    arrays instead."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    rng = np.random.default_rng(5)
+    streams = []
+    for seed in (21, 22, 23):
+        clean = _wrap_stream(61000, seed, groups=8, rows_per_group=900)
+        nrec = len(clean) // 11
+        cuts = sorted(set(int(x) for x in rng.integers(1, nrec, 120)))
+        out, last = bytearray(), 0
+        for c in cuts:
+            out += clean[11 * last:11 * c]
+            gap = int(rng.choice([30, 49, 60, 100, 200, 3100, 6100]))
+            pad = (-len(out)) % 3024 if rng.random() < 0.3 else 0       # some gaps end exactly on a tile edge
+            out += bytes(rng.choice(np.array([0x00, 0x7F, 0x40, 0xBF], np.uint8), gap + pad))
+            last = c
+        out += clean[11 * last:]
+        streams.append(bytes(out))
+    offs, lens, blob = [], [], bytearray()
+    for sbytes in streams:
+        while len(blob) % 16:
+            blob.append(0xEE)
+        offs.append(len(blob)); lens.append(len(sbytes)); blob += sbytes
+    blob += b"\xEE" * 64
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
+    pipe.set_layout(offs, lens)
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    for f, sbytes in enumerate(streams):
+        rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+        assert (int(st[f, 2]), int(st[f, 3]), int(st[f, 15])) == (v, d, 0)
+        rows = pipe.frame_rows(f, st)
+        for k in rows_o:
+            assert np.array_equal(rows[k], rows_o[k]), (f, k)
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+        assert ng >= 8 and nb > 20 and len(kept_o["ue"]) > 100
+        assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), f
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
