@@ -10,6 +10,13 @@
 // so the winner is one of the two circular neighbours of clk mod CYCLE among the group's distinct
 // baseline phases.  Each group's phases are sorted once (ties keep the earliest baseline), then
 // every row does one binary search instead of a pass over all baselines.  All integer arithmetic.
+//
+// Two drivers share the search.  The dense one (slam_correct: int32 columns, rows 0..n-1) works per block of 1024
+// rows: k_rows_summarize -> k_tile_scan -> k_rows_groups -> k_bl_sort[_small] -> k_rows_correct -> k_tile_scan ->
+// k_rows_emit_kept (ordered compaction).  The batched one works on the tile-slotted records the framing pass
+// leaves, with the per-tile bits, counts and baseline payloads it already derived: k_tile_bits (only for what
+// the framing pass could not do) -> k_tile_scan -> k_tile_groups -> k_bl_sort[_small] -> k_rows_finish, which
+// writes the kept rows into per-block slots, so neither a corrected-BS column nor a second scan is needed.
 
 #include <type_traits>
 
