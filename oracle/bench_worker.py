@@ -1,0 +1,39 @@
+"""CPU-baseline worker of bench.py (test infrastructure, like everything under oracle/; never on a product path).
+
+    python oracle/bench_worker.py B N first_frame n_frames tile
+
+Regenerates n_frames synthetic frames with the NumPy generator (byte-identical to the device generator), then
+times the CPU oracle over them — hex unpack, sequential record scan, brute-force baseline search, pivot, blur,
+raster — on this one process / one core, and prints {"n": n_frames, "dt": seconds} as JSON.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "slam-process_amd"))
+
+
+def main():
+    B, N, first, n, tile = (int(x) for x in sys.argv[1:6])
+    import numpy as np
+    from oracle import slam_oracle as O
+    from slamhip import synth
+    with open(os.path.join(ROOT, "slam-process_amd", "slamhip", "beam_angle.json")) as fh:
+        mapping = {int(k): float(v) for k, v in json.load(fh).items()}
+    lut = np.load(os.path.join(ROOT, "slam-process_amd", "slamhip", "viridis_lut.npy"))
+    texts = [synth.make_frame_text(B, N, first + i).tobytes() for i in range(n)]
+    t0 = time.perf_counter()
+    for t in texts:
+        by = O.read_bytes(t)
+        rows, v, d = O.parse_groups(by)
+        kept, ng, nb = O.filter_corrected(rows["flag"], rows["ue"], rows["bs"], rows["rss"], rows["clk"])
+        mat, aod, aoa, s, c = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"], mapping)
+        O.render(mat, aod, aoa, lut, use_log=False, blur_sigma=1.0, W=tile, H=tile)
+    print(json.dumps(dict(n=n, dt=time.perf_counter() - t0)))
+
+
+if __name__ == "__main__":
+    main()
