@@ -556,3 +556,39 @@ def test_batched_correction_with_record_free_gaps(mapping, lut):
         kept = pipe.frame_kept(f, st)
         for k in kept_o:
             assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
+
+
+def test_batched_api_rejects_bad_arguments(mapping, lut):
+    """slam_process_frames_dev refuses shapes it cannot run instead of faulting: short row arrays, misaligned row
+    arrays, a missing LUT, a cycle out of range."""
+    import ctypes as C
+    import torch
+    from slamhip import _lib, synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 4, 512, 2
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N)
+    pipe = FramePipeline(F, tl, tile_w=64, tile_h=64, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)                                           # the untouched batch works
+    good = {k: getattr(pipe.bt, k) for k in ("row_cap", "flag_dev", "lut_dev", "cycle")}
+
+    def expect_error(field, value, code):
+        setattr(pipe.bt, field, value)
+        try:
+            with pytest.raises(_lib.SlamError) as ei:
+                pipe.run(text)
+            assert ei.value.code == code, (field, ei.value)
+        finally:
+            setattr(pipe.bt, field, good[field])
+
+    expect_error("row_cap", 16, _lib.E_INVALID)
+    expect_error("row_cap", good["row_cap"] + 8, _lib.E_INVALID)          # not a multiple of 16
+    expect_error("flag_dev", good["flag_dev"] + 4, _lib.E_INVALID)
+    expect_error("lut_dev", None, _lib.E_INVALID)
+    expect_error("cycle", 0, _lib.E_INVALID)
+    expect_error("cycle", (1 << 30) + 1, _lib.E_INVALID)
+    pipe.run(text)                                           # and still works afterwards
+    st = pipe.stats_host()
+    assert int(st[0, 2]) > 0 and int(st[0, 6]) > 0
