@@ -872,7 +872,12 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                 const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo_all];
                 const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo_all];
                 if (nd <= 64) {
-                    // the whole table in registers, one entry per lane; lookups are lane permutes (no LDS banks)
+                    // the whole table in registers, one entry per lane; lookups are lane permutes (no LDS banks).
+                    // A wave none of whose rows belongs to this group skips it (no barrier on this path): in a
+                    // block that spans two groups only the wave holding the boundary searches twice.
+                    if (!__any((fl[0] != 1 && gi[0] == gg) || (fl[1] != 1 && gi[1] == gg) || (fl[2] != 1 && gi[2] == gg) ||
+                               (fl[3] != 1 && gi[3] == gg)))
+                        continue;
                     if (in_reg_group != gg) {
                         const uint32_t lane = lane_id();
                         t_r = lane < nd ? grb[lane] : 0xFFFFFFFFu;
