@@ -52,6 +52,9 @@ def parse_args():
     p.add_argument("--no-gather", action="store_true", help="same as --gather none")
     p.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                   help="N>1 process group; gloo (collectives staged through host memory) only to rehearse the "
+                        "multi-rank control flow on a box with fewer GPUs than ranks")
     return p.parse_args()
 
 
@@ -92,11 +95,27 @@ def main():
     cpu_line = None
     if rank == 0 and world == 1 and a.cpu_frames > 0:      # before anything here initialises the GPU
         cpu_line = cpu_baseline(a.beams, a.samples, a.cpu_frames, a.tile)
+    local %= max(1, torch.cuda.device_count())          # ranks share GPUs only in a --backend gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def gather_to_root(src, out_list):
+        """dist.gather of a device tensor to rank 0 (RCCL; through host memory under gloo)."""
+        if a.backend == "nccl":
+            dist.gather(src, out_list if rank == 0 else None, dst=0)
+            return
+        host = src.cpu()
+        tmp = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, tmp, dst=0)
+        if rank == 0:
+            for o, t in zip(out_list, tmp):
+                o.copy_(t)
 
     from slamhip import _lib, synth
     from slamhip.pipeline import FramePipeline, default_mapping, expand_compact, synth_frames, viridis_lut
@@ -137,7 +156,7 @@ def main():
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
                 src = pipe.tiles[slot:slot + F] if gmode == "tiles" else pipe.compact[cslot]
-                dist.gather(src, recv if rank == 0 else None, dst=0)
+                gather_to_root(src, recv)
                 done = torch.cuda.Event()
                 done.record(comm_stream)
             # the slot is reused two steps later: compute must wait for this gather
@@ -174,12 +193,12 @@ def main():
         # after the clock: the last batch's full tiles of every rank travel once, and rank 0 repaints the compact
         # results it received for that batch; both must be the same bytes
         full = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(pipe.tiles[:F], full, dst=0)
+        gather_to_root(pipe.tiles[:F], full)
         if rank == 0:
             gather_verified = all(bool(torch.equal(expand_compact(recv[r], F, a.tile, a.tile), full[r])) for r in range(world))
             del full
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
