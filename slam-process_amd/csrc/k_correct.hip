@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, ui
 
 // Group table (first row, first baseline of every group), baseline list, optional gid per row.
 template <typename T8, typename T32>
-__global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
+__global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint32_t rt_max,
                                                       const uint32_t *rt_gbase, const uint32_t *rt_bbase,
                                                       correct_ws ws, int32_t *gid_out, const uint32_t *stats)
 {
@@ -640,7 +640,7 @@ __device__ __forceinline__ bool best_phase(const RB *rb, const PAY *pay, uint32_
 
 // Per row: nearest baseline phase of its group -> corrected BS or "none"; kept count per tile.
 template <typename T8, typename T32, typename TC>
-__global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uint32_t rt_max, int one_group,
+__global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uint32_t rt_max,
                                                        const uint32_t *rt_gbase, correct_ws ws, TC *corr,
                                                        correct_params prm, uint32_t *rt_nkept,
                                                        const uint32_t *stats)
@@ -1137,7 +1137,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
                 (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1,
                 (uint32_t)ROWS_PER_BLOCK);
-    SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
+    SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), ws, in.row_cap, prm, stats,
                 tile_bits());
@@ -1150,7 +1150,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                     rt_max, ws.rt_nbound, ws, prm_k, out, stats);
         return SLAM_OK;
     }
-    SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, og, ws.rt_nbound, ws,
+    SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, ws.rt_nbound, ws,
                 corr, prm_k, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,
                 (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ROWS_PER_BLOCK);

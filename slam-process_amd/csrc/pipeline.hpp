@@ -39,8 +39,8 @@ struct frame_ws {               // device scratch of the framing stage
     uint64_t dec_stride;
     static uint64_t dec_stride_for(uint32_t nt_max) { return (uint64_t)nt_max * FRAME_TILE + 256; }
     frame_desc *fdesc;          // [F]
-    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[5]);
-    void bind(uint8_t *base, const size_t off[5], uint32_t nt_max);
+    static void plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[6]);
+    void bind(uint8_t *base, const size_t off[6], uint32_t nt_max);
 };
 
 // What the correction needs to know about neighbouring rows, produced per framing tile while the tile's records
