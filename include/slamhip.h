@@ -230,7 +230,9 @@ int slam_synth_frames_dev(slam_ctx *ctx, uint8_t *text_dev, uint64_t frame_strid
 int slam_copy_probe_dev(slam_ctx *ctx, void *dst_dev, const void *src_dev, size_t n);
 /* Read-only probes shaped like the framing kernels' loads: every wave reads its own contiguous chunk of
  * src (n bytes) with 12 loads per lane.  mode 1: 16-byte loads at a 12-byte lane stride; 2: 12-byte loads;
- * 3: 16-byte loads at a 16-byte lane stride.  scratch_dev: at least 4 writable bytes. */
+ * 3: 16-byte loads at a 16-byte lane stride.  scratch_dev: at least 4 writable bytes.
+ * Copy-like probes: modes 10/11/12 read n bytes and write n bytes to scratch_dev (plain / non-temporal stores /
+ * non-temporal loads and stores); modes 20/21/22 read n bytes and write n/3 (the framing kernel's 3:1 mix). */
 int slam_read_probe_dev(slam_ctx *ctx, void *scratch_dev, const void *src_dev, size_t n, int mode);
 
 /* Timing of the kernels a ctx launched since slam_timing_reset: per kernel name, launches and
