@@ -407,6 +407,8 @@ def test_reject_positions_and_log_lines(golden_dir, ops):
     streams = {k: np.array(e["bytes"], np.uint8) for k, e in doc.items()}
     for i, sb in enumerate(_hostile_streams()):
         streams[f"hostile_{i}"] = np.frombuffer(sb, np.uint8)
+    for name in ("log0", "log1", "log2"):                      # truncated real captures (121 / 148 / 238 discards)
+        streams[name] = np.load(os.path.join(golden_dir, name + ".npz"))["bytes"].astype(np.uint8)
 
     class Capture(logging.Handler):
         def __init__(self):
