@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 // group ids come from the bits k_rows_summarize left per 4 entries, the four rows of a thread search their
 // group's LDS-staged phase table in lock step (fixed trip count over the table padded to a power of two), and a
 // kept row goes straight to the front of its block's entries.
-constexpr int FIN_TPB = 4;            // consecutive blocks of entries one workgroup of k_rows_finish walks
+constexpr int FIN_TPB = 3;            // consecutive blocks of entries one workgroup of k_rows_finish walks
 
 template <typename V, typename T>
 __device__ __forceinline__ void unpack4(const V &q, T v[4])
