@@ -1126,7 +1126,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                     ws.rt_nbound, stats);
         SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), w2, in.row_cap, prm,
                     stats, in.bits);
-        SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), w2, in.row_cap, prm, stats,
+        SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), w2, in.row_cap, prm, stats,
                     in.bits, WAVE_SORT_MAX);
         SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
                     rt_max, ws.rt_nbound, w2, prm_k, out, stats);
@@ -1141,7 +1141,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), ws, in.row_cap, prm, stats,
                 tile_bits());
-    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : 256, F), dim3(256), ws, in.row_cap, prm, stats,
+    SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), ws, in.row_cap, prm, stats,
                 tile_bits(), WAVE_SORT_MAX);
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
