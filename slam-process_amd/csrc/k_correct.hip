@@ -418,13 +418,31 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
         if (m > WAVE_SORT_MAX) continue;
         uint32_t q = 0, r = 0, bsv = 0;
         unsigned long long key = ~0ull;
+        unsigned long long pay = 0;
+        if (bits.pay) {
+            // baseline b0 + lane out of the per-tile lists: the tiles of the group's rows each hold a few; with their
+            // bases in one register per lane the owning tile is a count over lane broadcasts, no dependent loads
+            const uint32_t T0 = ws.grp_row[gs + g] / SLOT_ROWS, T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS;
+            const uint32_t ntile = T1 - T0 + 1;
+            if (ntile <= 64) {
+                const uint32_t *bbase = bits.nbase + (size_t)f * bits.stride;
+                const uint32_t mine = lane < ntile ? bbase[T0 + lane] : 0xFFFFFFFFu;
+                const uint32_t j = b0 + lane;
+                uint32_t owner = 0, obase = (uint32_t)__shfl((int)mine, 0, 64);
+                for (uint32_t t = 1; t < ntile; t++) {            // last tile whose base is <= j
+                    const uint32_t bt = (uint32_t)__shfl((int)mine, (int)t, 64);
+                    if (bt <= j) { owner = t; obase = bt; }
+                }
+                if (lane < m) pay = bits.pay[((size_t)f * bits.stride + T0 + owner) * BL_PAY_CAP + (j - obase)];
+            } else if (lane < m) {
+                pay = baseline_from_tiles(bits, f, b0 + lane, T0, T1);
+            }
+        }
         if (lane < m) {
             int32_t clk;
             if (bits.pay) {
-                const uint32_t T0 = ws.grp_row[gs + g] / SLOT_ROWS, T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS;
-                const unsigned long long p = baseline_from_tiles(bits, f, b0 + lane, T0, T1);
-                clk = (int32_t)(uint32_t)p;
-                bsv = (uint32_t)((p >> 32) & 0xFFu);
+                clk = (int32_t)(uint32_t)pay;
+                bsv = (uint32_t)((pay >> 32) & 0xFFu);
             } else {
                 clk = ws.bl_clk[bsb + b0 + lane];
                 bsv = (uint32_t)ws.bl_bs[bsb + b0 + lane];
