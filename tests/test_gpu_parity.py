@@ -345,6 +345,10 @@ def _hostile_streams():
     good = b"".join(rec(i & 1, 0x33, 0x0C, 1563 + 61000 * i, 20000 + i) for i in range(900))   # UE byte 0x33, BS byte 0xCC
     for cut in list(range(3024 - 60, 3024 + 70, 7)) + [6048 - 5, 6048, 6048 + 5]:
         out.append(good[:cut])
+    for cut in (0, 1, 5, 10, 11, 12, 22, 47, 48, 49, 59, 60, 100):        # frames shorter than a run or two
+        out.append(good[:cut])
+    out.append(bytes([0x33]))
+    out.append(bytes([0xCC]) * 11)
     out.append(bytes([0x33]) * 7000)                                   # flag bytes only
     out.append(bytes([0xCC, 0x33]) * 3500)
     out.append(bytes(rng.integers(0, 256, 9000, dtype=np.uint8)))      # noise
