@@ -250,3 +250,19 @@ def test_per_group_log_lines_follow_the_reference(tmp_path):
     finally:
         root.handlers[:] = old_handlers
         root.setLevel(old_level)
+
+
+def test_every_golden_edge_text_through_the_batched_path():
+    """The reference's edge cases (empty, prefix only, no trailing space, 0x tokens, odd whitespace, invalid UTF-8,
+    truncated tails, resync garbage ...) as one ragged batch: strict texts take the single-pass kernel, the rest
+    are flagged and redone from the general tokenizer's bytes; rows and counters as the reference gave them."""
+    from slamhip.batch import process_texts
+    edge = json.load(open(os.path.join(GOLDEN, "edge_streams.json")))
+    names = sorted(edge)
+    res = process_texts([bytes(edge[k]["text"]) for k in names], tile=32)
+    assert len(res) == len(names) >= 20
+    for k, r in zip(names, res):
+        e = edge[k]
+        assert (int(r["stats"][2]), int(r["stats"][3])) == (e["valid"], e["discarded"]), k
+        got = np.stack([r["rows"][c].astype(np.int64) for c in ("flag", "ue", "bs", "rss", "clk")], 1)
+        assert np.array_equal(got, np.asarray(e["rows"], np.int64).reshape(-1, 5)), k
