@@ -229,6 +229,65 @@ def filter_group_py(rows, baselines, cycle=CYCLE, tol=TOL, mod_base=MOD_BASE):
     return out
 
 
+def correct_table_nulls_py(rows, filtered: bool, cycle=CYCLE, tol=TOL, mod_base=MOD_BASE):
+    """The correction drivers on a table whose cells may be None (a NaN after _coerce_types :35-40), as a
+    literal loop (small inputs).  Returns (gid list, dict(result=...) or dict(error="ValueError", message=...)).
+
+    Null semantics of the reference: a row after a null UE starts a group and a null UE never does (:45);
+    a null FLAG is neither 0 nor 1 for the baseline mask (:53) and counts as 0 in the row loops (:84, :144);
+    a null RSS equals nothing (:53); a null CLK skips the row (:91-94, :149-151); every other int() of a
+    null cell raises ValueError (:58-59, :86-107, :164-167).  filtered=True gives the kept rows of
+    process_excel_filtered (:186-198), False the Corrected_BS_Beam column of process_excel (:125-134).
+    """
+    def to_int(v):
+        if v is None:
+            raise ValueError("cannot convert float NaN to integer")
+        return int(v)
+
+    n = len(rows)
+    gid, g = [], -1
+    for i, r in enumerate(rows):
+        prev = rows[i - 1][1] if i else None
+        if i == 0 or prev is None or (r[1] is not None and prev > r[1]):
+            g += 1
+        gid.append(g)
+    try:
+        kept, col = [], [None] * n
+        start = 0
+        while start < n:
+            end = start
+            while end < n and gid[end] == gid[start]:
+                end += 1
+            bl = []
+            for i in range(start + 1, end):
+                f, pf, rs, prs = rows[i][0], rows[i - 1][0], rows[i][3], rows[i - 1][3]
+                if f == 1 and pf == 0 and rs is not None and prs is not None and rs == prs:
+                    clk_b = to_int(rows[i - 1][4])
+                    bl.append((clk_b, to_int(rows[i][2])))
+            for i in range(start, end):
+                flag, ue, bs, rss, clk = rows[i]
+                flag = 0 if flag is None else int(flag)
+                best = None
+                if flag != 1 and bl and clk is not None:
+                    for clk_b, bs_b in bl:
+                        d = int(clk) - clk_b
+                        k = int(round(d / cycle))
+                        resid = abs(d - k * cycle)
+                        if resid <= tol and (best is None or resid < best[0]):
+                            best = (resid, (bs_b + k) % mod_base)
+                if filtered:
+                    if best is not None:
+                        kept.append([to_int(ue), int(best[1]), to_int(rss), to_int(clk)])
+                else:
+                    col[i] = int(best[1]) if best is not None else to_int(bs)
+            start = end
+        if filtered and not kept:
+            raise ValueError("未产生任何可修正数据行，输出为空")
+        return gid, dict(result=kept if filtered else col)
+    except ValueError as e:
+        return gid, dict(error="ValueError", message=str(e))
+
+
 # ---------------------------------------------------------------------------
 # a8-a10  mapping table, map_angles, compute_rssi_matrix
 # ---------------------------------------------------------------------------

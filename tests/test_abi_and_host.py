@@ -127,6 +127,33 @@ def test_drop_in_modules_mirror_the_reference_signatures():
                 assert getattr(mine, name) == obj, f"{mod}.{name}"
 
 
+def test_stand_ins_for_empty_cells_reproduce_the_group_rule():
+    """Host logic of the correction drop-in: the integers that stand in for null UE / RSS / FLAG cells make plain
+    integer rules (previous UE > UE; RSS equal; FLAG == 0 / == 1) agree with the reference's NaN rules on every
+    table of the null-cell fixture."""
+    import importlib.util
+    import pandas as pd
+    spec = importlib.util.spec_from_file_location("mine_bs_beam_correction_enc", os.path.join(PKG, "bs_beam_correction.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    doc = json.load(open(os.path.join(GOLDEN, "null_tables.json"), encoding="utf-8"))
+    for name, e in doc.items():
+        cols = [[np.nan if v is None else v for v in c] for c in zip(*e["rows"])]
+        df = pd.DataFrame(dict(zip(B._IN_COLS, cols)), dtype=np.float64)
+        (f, u, b, r, c), nulls = B._encode(df)
+        assert nulls is not None or not any(v is None for row in e["rows"] for v in row), name
+        u = u.astype(np.int64)
+        gid = np.cumsum(np.concatenate(([True], u[:-1] > u[1:]))) - 1
+        assert gid.tolist() == e["gid"], name
+        if nulls is None:
+            continue
+        nf, nu, nb, nr, nc = nulls
+        same = r[1:] == r[:-1]
+        assert not (same & (nr[1:] | nr[:-1])).any(), name          # a null RSS equals nothing
+        assert not np.isin(f[nf], (0, 1)).any(), name               # a null FLAG is neither 0 nor 1
+        assert all(np.isfinite(x).all() and -2 ** 31 <= x.min() and x.max() < 2 ** 31 for x in (f, u, b, r, c)), name
+
+
 def test_file_balancing_and_sharding():
     from slamhip import dist as D
     assert D.shard_frames(10, 1, 4) == [1, 5, 9]

@@ -266,3 +266,91 @@ def test_every_golden_edge_text_through_the_batched_path():
         assert (int(r["stats"][2]), int(r["stats"][3])) == (e["valid"], e["discarded"]), k
         got = np.stack([r["rows"][c].astype(np.int64) for c in ("flag", "ue", "bs", "rss", "clk")], 1)
         assert np.array_equal(got, np.asarray(e["rows"], np.int64).reshape(-1, 5)), k
+
+
+def test_tables_with_empty_cells_follow_the_reference(tmp_path):
+    """Workbooks whose cells are partly empty: both drivers give the rows, the failure and the log lines the
+    reference's own functions gave (tests/golden/null_tables.json), and _detect_groups the same group ids."""
+    import pandas as pd
+    import bs_beam_correction as B
+    import serial_hex_to_excel_v3 as S
+    from slamhip import xlsx
+    doc = json.load(open(os.path.join(GOLDEN, "null_tables.json"), encoding="utf-8"))
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.DEBUG)
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(f"{record.levelname} {record.getMessage()}")
+
+    root = logging.getLogger()
+    old_handlers, old_level = root.handlers[:], root.level
+    root.setLevel(logging.DEBUG)
+    try:
+        for name, e in doc.items():
+            cols = [list(c) for c in zip(*e["rows"])]
+            root.handlers[:] = []
+            df = B._coerce_types(pd.DataFrame(dict(zip(S.HEADER, cols))))
+            assert B._detect_groups(df).tolist() == e["gid"], name
+            for key in ("filtered", "inplace"):
+                p = tmp_path / f"{name}_{key}.xlsx"
+                xlsx.write_table(str(p), S.HEADER, cols, sheet="Parsed")
+                cap = Capture()
+                root.handlers[:] = [cap]
+                want = e[key]
+                try:
+                    if key == "filtered":
+                        t = xlsx.read_table(B.process_excel_filtered(str(p)))
+                        got = [list(r) for r in zip(*(t[c] for c in (B.OUT_UE, B.OUT_BS, B.OUT_RSS, B.OUT_CLK)))]
+                    else:
+                        B.process_excel(str(p))
+                        got = [None if v is None else int(v) for v in xlsx.read_table(str(p))[B.OUT_COL]]
+                    assert "error" not in want, (name, key)
+                    assert got == want["result"], (name, key)
+                except ValueError as ex:
+                    assert want.get("error") == "ValueError" and str(ex) == want["message"], (name, key, str(ex))
+                lines = [ln for ln in cap.lines if "已生成" not in ln and "已写回" not in ln]
+                assert lines == want["log"], (name, key)
+    finally:
+        root.handlers[:] = old_handlers
+        root.setLevel(old_level)
+
+
+def test_group_functions_with_empty_cells():
+    """_identify_baselines / _correct_group / _filter_group_corrected on one-group tables holding an empty cell,
+    against the oracle's literal loop (itself pinned on the reference by the same fixture)."""
+    import pandas as pd
+    import bs_beam_correction as B
+    import serial_hex_to_excel_v3 as S
+    doc = json.load(open(os.path.join(GOLDEN, "null_tables.json"), encoding="utf-8"))
+    n_checked = 0
+    for name, e in doc.items():
+        if len(set(e["gid"])) != 1:
+            continue
+        df = B._coerce_types(pd.DataFrame(dict(zip(S.HEADER, [list(c) for c in zip(*e["rows"])]))))
+        _, want_f = O.correct_table_nulls_py(e["rows"], True)
+        _, want_p = O.correct_table_nulls_py(e["rows"], False)
+        try:
+            bl = B._identify_baselines(df)
+        except ValueError as ex:
+            assert str(ex) == "cannot convert float NaN to integer"
+            assert want_p.get("error") == "ValueError" and want_f.get("error") == "ValueError", name
+            continue
+        n_checked += 1
+        try:
+            got = [int(v) for v in B._correct_group(df, bl)[B.OUT_COL].tolist()]
+            assert got == want_p["result"], name
+        except ValueError:
+            assert want_p.get("error") == "ValueError", name
+        try:
+            out = B._filter_group_corrected(df, bl)
+            got = out.to_numpy().tolist()
+            if want_f.get("error"):
+                assert got == [] and "输出为空" in want_f["message"], name
+            else:
+                assert got == want_f["result"], name
+        except ValueError:
+            assert want_f.get("message") == "cannot convert float NaN to integer", name
+    assert n_checked >= 20

@@ -152,3 +152,16 @@ def test_reject_positions_and_log_lines_match_reference(golden_dir):
         assert (v, d) == (e["valid"], e["discarded"]), name
         assert len(pos) == d
         assert drop.reject_lines(by.tolist(), pos) == e["lines"], name
+
+
+def test_oracle_null_cells_match_the_reference():
+    """Tables with empty cells: group ids, outputs and failures as the reference's drivers gave them
+    (tests/golden/make_null_tables.py)."""
+    doc = json.load(open(os.path.join(GOLDEN, "null_tables.json"), encoding="utf-8"))
+    assert len(doc) >= 80
+    for name, e in doc.items():
+        for key, filt in (("filtered", True), ("inplace", False)):
+            gid, got = O.correct_table_nulls_py(e["rows"], filt)
+            assert gid == e["gid"], name
+            want = {k: v for k, v in e[key].items() if k != "log"}
+            assert got == want, (name, key)
