@@ -57,6 +57,14 @@ const char *slam_version(void);
 int slam_hex_unpack(slam_ctx *ctx, const uint8_t *text, size_t n_text,
                     uint8_t *bytes_out, size_t cap, size_t *n_bytes);
 
+/* Diagnostics of a1: the tokens _read_bytes skips, in text order — one per "跳过非16进制单字节token[idx]" log line
+ * (serial_hex_to_excel_v3.py:22, :26-28).  index_out = the token's index among all tokens of the text (the
+ * reference's enumerate index), [begin_out, end_out) = the bytes of the text from the token's first character
+ * to the whitespace that ends it; decoding that span as UTF-8 with errors ignored gives the token.
+ * n_rejects is always set to their number; SLAM_E_CAPACITY when it exceeds cap (nothing is copied then). */
+int slam_token_rejects(slam_ctx *ctx, const uint8_t *text, size_t n_text,
+                       uint32_t *index_out, uint32_t *begin_out, uint32_t *end_out, size_t cap, size_t *n_rejects);
+
 /* ---- a2: bytes -> records ------------------------------------------------------------------
  * Replaces _parse_groups (serial_hex_to_excel_v3.py:41-103): the resynchronising scan for
  * 11-byte records FLAG UE BS CLK0..4 RSS0..2.  Outputs are struct-of-arrays in record order;

@@ -103,6 +103,16 @@ def read_bytes_py(text: bytes) -> np.ndarray:
     return np.array(out, dtype=np.uint8)
 
 
+def skipped_tokens_py(text: bytes) -> List[Tuple[int, str]]:
+    """(token index, token) for every token _read_bytes skips (:22-28), through CPython's decoder and split."""
+    out = []
+    for idx, t in enumerate(bytes(text).decode("utf-8", errors="ignore").split()):
+        s = t[2:] if len(t) == 4 and t[:2] == "0x" else t
+        if not (len(s) == 2 and all(c in "0123456789abcdefABCDEF" for c in s)):
+            out.append((idx, t))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # a2  serial_hex_to_excel_v3._parse_groups  (:41-103)
 # ---------------------------------------------------------------------------

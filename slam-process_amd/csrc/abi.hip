@@ -327,6 +327,35 @@ extern "C" int slam_hex_unpack(slam_ctx *ctx, const uint8_t *text, size_t n_text
     return SLAM_OK;
 }
 
+extern "C" int slam_token_rejects(slam_ctx *ctx, const uint8_t *text, size_t n_text, uint32_t *index_out,
+                                  uint32_t *begin_out, uint32_t *end_out, size_t cap, size_t *n_rejects)
+{
+    REQUIRE_CTX(ctx);
+    if ((!text && n_text) || !n_rejects) return slam_fail(ctx, SLAM_E_INVALID, "slam_token_rejects: null argument");
+    if (n_text > 0xFFFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "text larger than 4 GiB");
+    *n_rejects = 0;
+    if (n_text == 0) return SLAM_OK;
+    const uint32_t cap_dev = (uint32_t)std::min<size_t>(cap, n_text);      // a token takes at least one byte
+    ws_plan p;
+    size_t o_text = p.add(n_text + 32), o_cnt = p.add(4), o_out[3], o_tok = p.add(token_rejects_ws_bytes(n_text));
+    for (int i = 0; i < 3; i++) o_out[i] = p.add((size_t)cap_dev * 4 + 4);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    SLAM_TRY(h2d(ctx, b + o_text, text, n_text));
+    SLAM_TRY(token_rejects(ctx, b + o_text, n_text, (uint32_t *)(b + o_out[0]), (uint32_t *)(b + o_out[1]),
+                           (uint32_t *)(b + o_out[2]), cap_dev, (uint32_t *)(b + o_cnt), b + o_tok));
+    SLAM_TRY(d2h(ctx, ctx->pinned, b + o_cnt, 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = ctx->pinned[0];
+    *n_rejects = n;
+    if (n > cap || (n && (!index_out || !begin_out || !end_out)))
+        return slam_fail(ctx, SLAM_E_CAPACITY, "slam_token_rejects: need room for %zu tokens, have %zu", n, cap);
+    uint32_t *outs[3] = {index_out, begin_out, end_out};
+    for (int i = 0; i < 3; i++) SLAM_TRY(d2h(ctx, outs[i], b + o_out[i], n * 4));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // a2: bytes -> records, and a1+a2 fused
 // ------------------------------------------------------------------------------------------------------

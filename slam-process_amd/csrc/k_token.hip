@@ -89,8 +89,9 @@ __global__ __launch_bounds__(1024) void k_tok_scan(uint32_t *cnt, uint32_t n_til
     if (threadIdx.x == 0) *total = carry;
 }
 
+// `pos` (optional): the byte offset each character starts at, for the diagnostics pass below
 __global__ __launch_bounds__(256) void k_tok_write_chars(const uint8_t *t, size_t n, const uint32_t *tile_off,
-                                                          uint8_t *cls)
+                                                          uint8_t *cls, uint32_t *pos)
 {
     __shared__ uint32_t sh[17];
     const size_t base = (size_t)blockIdx.x * TOK_TILE + (size_t)threadIdx.x * 16;
@@ -103,7 +104,10 @@ __global__ __launch_bounds__(256) void k_tok_write_chars(const uint8_t *t, size_
     uint32_t tot;
     uint32_t o = tile_off[blockIdx.x] + block_excl_scan(cnt, sh, &tot);
     for (int k = 0; k < 16; k++)
-        if (c[k] != C_DROP) cls[o++] = c[k];
+        if (c[k] != C_DROP) {
+            if (pos) pos[o] = (uint32_t)(base + k);
+            cls[o++] = c[k];
+        }
 }
 
 // ---- pass C/D: token starts -> bytes ----------------------------------------------------------------------
@@ -156,7 +160,104 @@ __global__ __launch_bounds__(256) void k_tok_write_bytes(const uint8_t *cls, con
         if (v[k] >= 0) out[o++] = (uint8_t)v[k];
 }
 
+// ---- diagnostics: the tokens _read_bytes skips (:26-28), with their index among all tokens ---------------
+__device__ __forceinline__ bool token_starts(const uint8_t *cls, uint32_t k)
+{
+    return cls[k] != C_SPACE && (k == 0 || cls[k - 1] == C_SPACE);
+}
+
+__global__ __launch_bounds__(256) void k_tok_count_rejects(const uint8_t *cls, const uint32_t *m_dev, uint32_t *cnt_tok,
+                                                            uint32_t *cnt_rej)
+{
+    __shared__ uint32_t sh[8];
+    const uint32_t m = *m_dev;
+    const uint32_t base = blockIdx.x * TOK_TILE + threadIdx.x * 16;
+    uint32_t ct = 0, cr = 0;
+    for (int k = 0; k < 16; k++)
+        if (base + k < m && token_starts(cls, base + k)) {
+            ct++;
+            cr += token_at(cls, base + k, m) < 0;
+        }
+    ct = wave_sum(ct);
+    cr = wave_sum(cr);
+    if (lane_id() == 0) { sh[threadIdx.x >> 6] = ct; sh[4 + (threadIdx.x >> 6)] = cr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt_tok[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        cnt_rej[blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7];
+    }
+}
+
+// One entry per skipped token, in text order: its index among all tokens and the byte span [begin, end) from
+// its first character to the whitespace character that ends it (bytes the decoder ignores included).
+__global__ __launch_bounds__(256) void k_tok_write_rejects(const uint8_t *cls, const uint32_t *pos, const uint32_t *m_dev,
+                                                            uint32_t n_text, const uint32_t *off_tok, const uint32_t *off_rej,
+                                                            uint32_t cap, uint32_t *out_idx, uint32_t *out_begin,
+                                                            uint32_t *out_end)
+{
+    __shared__ uint32_t sh_t[17], sh_r[17];
+    const uint32_t m = *m_dev;
+    const uint32_t base = blockIdx.x * TOK_TILE + threadIdx.x * 16;
+    uint32_t starts = 0, rej = 0;
+    for (int k = 0; k < 16; k++)
+        if (base + k < m && token_starts(cls, base + k)) {
+            starts |= 1u << k;
+            if (token_at(cls, base + k, m) < 0) rej |= 1u << k;
+        }
+    uint32_t tot;
+    uint32_t ti = off_tok[blockIdx.x] + block_excl_scan(__popc(starts), sh_t, &tot);
+    uint32_t ri = off_rej[blockIdx.x] + block_excl_scan(__popc(rej), sh_r, &tot);
+    for (int k = 0; k < 16; k++) {
+        if (!((starts >> k) & 1u)) continue;
+        if ((rej >> k) & 1u) {
+            if (ri < cap) {
+                uint32_t e = base + k + 1;
+                while (e < m && cls[e] != C_SPACE) e++;      // bounded by the class stream's length
+                out_idx[ri] = ti;
+                out_begin[ri] = pos[base + k];
+                out_end[ri] = e < m ? pos[e] : n_text;
+            }
+            ri++;
+        }
+        ti++;
+    }
+}
+
 }  // namespace
+
+size_t token_rejects_ws_bytes(size_t n_text)
+{
+    const size_t tiles = (n_text + TOK_TILE - 1) / TOK_TILE + 1;
+    return ((n_text + 255) & ~size_t(255)) + ((n_text * 4 + 255) & ~size_t(255)) + 3 * ((tiles * 4 + 255) & ~size_t(255)) + 256;
+}
+
+// Skipped tokens of a text: (token index, byte begin, byte end) triples into the three device arrays (room for
+// `cap` each), their number to n_dev[0] (it may exceed cap: then only the first cap were written).
+int token_rejects(slam_ctx *ctx, const uint8_t *text_dev, size_t n_text, uint32_t *idx_dev, uint32_t *begin_dev,
+                  uint32_t *end_dev, uint32_t cap, uint32_t *n_dev, uint8_t *ws)
+{
+    const uint32_t tiles = (uint32_t)((n_text + TOK_TILE - 1) / TOK_TILE);
+    if (tiles == 0) {
+        SLAM_HIP(ctx, hipMemsetAsync(n_dev, 0, 4, ctx->stream));
+        return SLAM_OK;
+    }
+    const size_t cnt_bytes = ((size_t)(tiles + 1) * 4 + 255) & ~size_t(255);
+    uint8_t *cls = ws;
+    uint32_t *pos = (uint32_t *)(ws + ((n_text + 255) & ~size_t(255)));
+    uint32_t *cnt_a = (uint32_t *)((uint8_t *)pos + ((n_text * 4 + 255) & ~size_t(255)));
+    uint32_t *cnt_t = (uint32_t *)((uint8_t *)cnt_a + cnt_bytes);
+    uint32_t *cnt_r = (uint32_t *)((uint8_t *)cnt_t + cnt_bytes);
+    uint32_t *m_dev = (uint32_t *)((uint8_t *)cnt_r + cnt_bytes);          // m, then the token total
+    SLAM_LAUNCH(ctx, "tok_count_chars", k_tok_count_chars, dim3(tiles), dim3(256), text_dev, n_text, cnt_a);
+    SLAM_LAUNCH(ctx, "tok_scan", k_tok_scan, dim3(1), dim3(1024), cnt_a, tiles, m_dev);
+    SLAM_LAUNCH(ctx, "tok_write_chars", k_tok_write_chars, dim3(tiles), dim3(256), text_dev, n_text, cnt_a, cls, pos);
+    SLAM_LAUNCH(ctx, "tok_count_rejects", k_tok_count_rejects, dim3(tiles), dim3(256), cls, m_dev, cnt_t, cnt_r);
+    SLAM_LAUNCH(ctx, "tok_scan", k_tok_scan, dim3(1), dim3(1024), cnt_t, tiles, m_dev + 1);
+    SLAM_LAUNCH(ctx, "tok_scan", k_tok_scan, dim3(1), dim3(1024), cnt_r, tiles, n_dev);
+    SLAM_LAUNCH(ctx, "tok_write_rejects", k_tok_write_rejects, dim3(tiles), dim3(256), cls, pos, m_dev, (uint32_t)n_text,
+                cnt_t, cnt_r, cap, idx_dev, begin_dev, end_dev);
+    return SLAM_OK;
+}
 
 size_t tokenize_ws_bytes(size_t n_text)
 {
@@ -178,7 +279,7 @@ int tokenize_general(slam_ctx *ctx, const uint8_t *text_dev, size_t n_text, uint
     uint32_t *m_dev = (uint32_t *)((uint8_t *)cnt_b + (((size_t)(tiles + 1) * 4 + 255) & ~size_t(255)));
     SLAM_LAUNCH(ctx, "tok_count_chars", k_tok_count_chars, dim3(tiles), dim3(256), text_dev, n_text, cnt_a);
     SLAM_LAUNCH(ctx, "tok_scan", k_tok_scan, dim3(1), dim3(1024), cnt_a, tiles, m_dev);
-    SLAM_LAUNCH(ctx, "tok_write_chars", k_tok_write_chars, dim3(tiles), dim3(256), text_dev, n_text, cnt_a, cls);
+    SLAM_LAUNCH(ctx, "tok_write_chars", k_tok_write_chars, dim3(tiles), dim3(256), text_dev, n_text, cnt_a, cls, (uint32_t *)nullptr);
     // the class stream has at most n_text elements: the same tile count covers it
     SLAM_LAUNCH(ctx, "tok_count_bytes", k_tok_count_bytes, dim3(tiles), dim3(256), cls, m_dev, cnt_b);
     SLAM_LAUNCH(ctx, "tok_scan", k_tok_scan, dim3(1), dim3(1024), cnt_b, tiles, n_out_dev);

@@ -188,3 +188,9 @@ int slam_gaussian_kernel_host(double sigma, std::vector<double> &k);
 int tokenize_general(slam_ctx *ctx, const uint8_t *text_dev, size_t n_text, uint8_t *bytes_dev, uint32_t *n_out_dev,
                      uint8_t *ws);
 size_t tokenize_ws_bytes(size_t n_text);
+// The tokens that tokenizer skips, for the reference's per-token log lines: (index among all tokens, byte
+// begin, byte end) per skipped token, in text order; n_dev[0] = how many there are.  `ws` must hold
+// token_rejects_ws_bytes(n_text) bytes of scratch.
+int token_rejects(slam_ctx *ctx, const uint8_t *text_dev, size_t n_text, uint32_t *idx_dev, uint32_t *begin_dev,
+                  uint32_t *end_dev, uint32_t cap, uint32_t *n_dev, uint8_t *ws);
+size_t token_rejects_ws_bytes(size_t n_text);

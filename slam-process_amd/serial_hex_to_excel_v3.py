@@ -6,10 +6,10 @@ Same module-level names, arguments, return values and CLI as the reference scrip
 libslamhip.so.  There is no CPU implementation behind these functions: without the library or a
 GPU they raise.
 
-Differences a caller can see: the workbook is written with the standard library (no openpyxl
-needed), and the per-token lines of _read_bytes are summarised.  The per-reject lines of
-_parse_groups are reproduced one by one: the device returns where the scan discarded a group, the
-reason and the hex dump of each line are read off the bytes at that index.
+Difference a caller can see: the workbook is written with the standard library (no openpyxl
+needed).  The log lines are reproduced one by one: the device returns which tokens _read_bytes
+skipped (index and byte span) and where the scan of _parse_groups discarded a group; the token
+text, the reason and the hex dump of each line are read off the input at those places.
 """
 from __future__ import annotations
 
@@ -43,8 +43,18 @@ def _read_bytes(path: Path, logger: logging.Logger) -> List[int]:
     """File -> list of byte values, token rules of the reference (:16, :18-36)."""
     raw = Path(path).read_bytes()
     data = ops.hex_unpack(raw)
-    logger.debug("hex tokens kept: %d of %d text bytes", len(data), len(raw))
+    if logger.isEnabledFor(logging.DEBUG):
+        for line in skipped_token_lines(raw):
+            logger.debug(line)
     return data.tolist()
+
+
+def skipped_token_lines(raw: bytes) -> List[str]:
+    """The line the reference logs for each token it skips (:27): the device returns the token's index and
+    byte span, the token text is that span decoded the way the file was (UTF-8, errors ignored)."""
+    idx, beg, end = ops.token_rejects(raw)
+    return ["跳过非16进制单字节token[%d]='%s'" % (int(i), bytes(raw[int(b):int(e)]).decode("utf-8", errors="ignore"))
+            for i, b, e in zip(idx.tolist(), beg.tolist(), end.tolist())]
 
 
 def _parse_groups(bytes_list: List[int], logger: logging.Logger) -> Tuple[List[Tuple[int, int, int, int, int]], int, int]:

@@ -24,7 +24,7 @@ TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
-    "slam_hex_unpack", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
+    "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_raster_dev", "slam_reserve_workspace",
     "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
         lib.slam_parse_records.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
         lib.slam_parse_text.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
         lib.slam_parse_rejects.argtypes = [vp, vp, sz, vp, sz, psz]
+        lib.slam_token_rejects.argtypes = [vp, vp, sz, vp, vp, vp, sz, psz]
         lib.slam_correct.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, u32, vp, vp, C.c_int64,
                                      vp, vp, vp, vp, psz, vp, vp, vp, vp, vp, psz, psz]
         lib.slam_pivot_mean.argtypes = [vp, vp, vp, vp, sz, vp, C.c_int, vp, vp, vp]

@@ -34,6 +34,23 @@ def hex_unpack(text, device: int = 0) -> np.ndarray:
     return out[: n.value].copy()
 
 
+def token_rejects(text, device: int = 0):
+    """The tokens _read_bytes skips: (index among all tokens, byte begin, byte end) uint32 arrays, in text order."""
+    c = _lib.ctx(device)
+    t = _u8(text)
+    n = C.c_size_t(0)
+    cap = 1024
+    while True:
+        idx, beg, end = (np.empty(cap, np.uint32) for _ in range(3))
+        rc = c.lib.slam_token_rejects(c.h, ptr(t) if len(t) else None, len(t), ptr(idx), ptr(beg), ptr(end), cap, C.byref(n))
+        if rc == _lib.E_CAPACITY and n.value > cap:
+            cap = n.value
+            continue
+        c.check(rc)
+        k = n.value
+        return idx[:k].copy(), beg[:k].copy(), end[:k].copy()
+
+
 def _parse(fn_name: str, src: np.ndarray, cap: int, device: int):
     c = _lib.ctx(device)
     flag = np.empty(cap, np.uint8)

@@ -598,3 +598,21 @@ def test_batched_api_rejects_bad_arguments(mapping, lut):
     pipe.run(text)                                           # and still works afterwards
     st = pipe.stats_host()
     assert int(st[0, 2]) > 0 and int(st[0, 6]) > 0
+
+
+def test_skipped_token_lines_follow_the_reference(ops):
+    """Per-token diagnostics of the tokenizer: index and byte span of every skipped token, turned into the line the
+    reference logs; golden lines captured from the reference's own _read_bytes (tests/golden/token_lines.json)."""
+    import serial_hex_to_excel_v3 as S
+    doc = json.load(open(os.path.join(GOLDEN, "token_lines.json"), encoding="utf-8"))
+    n_lines = 0
+    for name, e in doc.items():
+        raw = bytes(e["text"])
+        assert S.skipped_token_lines(raw) == e["lines"], name
+        assert len(ops.hex_unpack(raw)) == e["n_bytes"], name
+        n_lines += len(e["lines"])
+    assert n_lines > 1500
+    # a text that is one long run of skipped one-character tokens: more of them than the first request has room for
+    raw = b"z " * 5000
+    idx, beg, end = ops.token_rejects(raw)
+    assert idx.tolist() == list(range(5000)) and beg.tolist() == list(range(0, 10000, 2)) and (end - beg == 1).all()

@@ -165,3 +165,14 @@ def test_oracle_null_cells_match_the_reference():
             assert gid == e["gid"], name
             want = {k: v for k, v in e[key].items() if k != "log"}
             assert got == want, (name, key)
+
+
+def test_oracle_skipped_tokens_match_the_reference_log():
+    """The tokens _read_bytes skips and their enumerate index, as logged by the reference (tests/golden/make_token_lines.py)."""
+    doc = json.load(open(os.path.join(GOLDEN, "token_lines.json"), encoding="utf-8"))
+    assert len(doc) >= 40
+    for name, e in doc.items():
+        raw = bytes(e["text"])
+        lines = ["跳过非16进制单字节token[%d]='%s'" % it for it in O.skipped_tokens_py(raw)]
+        assert lines == e["lines"], name
+        assert len(O.read_bytes(raw)) == e["n_bytes"], name
