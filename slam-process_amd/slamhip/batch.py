@@ -62,9 +62,11 @@ def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, **p
     return res
 
 
-def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 1024, **pipeline_kwargs):
+def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 1024, gather_via_host: bool = False,
+                          **pipeline_kwargs):
     """Under torch.distributed: each rank processes the files `balance_files` gives it; rank 0 receives every
-    file's tile (list indexed like `paths`), other ranks None.  Without an initialised process group: all files."""
+    file's tile (list indexed like `paths`), other ranks None.  Without an initialised process group: all files.
+    `gather_via_host` stages the gather through host memory (for a gloo process group)."""
     import os
     import torch.distributed as dist
     from . import dist as D
@@ -81,7 +83,7 @@ def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 102
     tiles = torch.zeros((per, tile, tile, 4), dtype=torch.uint8, device=dev)
     for j, r in enumerate(res):
         tiles[j] = torch.from_numpy(r["tile"]).to(dev)
-    got = D.gather_tiles(tiles, dst=0)
+    got = D.gather_tiles(tiles.cpu() if gather_via_host else tiles, dst=0)
     if rank != 0:
         return None, res
     out: List[Optional[np.ndarray]] = [None] * len(paths)

@@ -154,6 +154,19 @@ def test_stand_ins_for_empty_cells_reproduce_the_group_rule():
         assert all(np.isfinite(x).all() and -2 ** 31 <= x.min() and x.max() < 2 ** 31 for x in (f, u, b, r, c)), name
 
 
+def test_png_writer_round_trips():
+    """The stdlib PNG writer: Pillow reads back the same RGBA bytes."""
+    import io
+    from PIL import Image
+    from slamhip import png
+    rng = np.random.default_rng(5)
+    for shape in ((1, 1, 4), (7, 13, 4), (256, 256, 4)):
+        t = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(png.encode_rgba(t)))), t)
+    with pytest.raises(ValueError):
+        png.encode_rgba(np.zeros((4, 4, 3), np.uint8))
+
+
 def test_file_balancing_and_sharding():
     from slamhip import dist as D
     assert D.shard_frames(10, 1, 4) == [1, 5, 9]

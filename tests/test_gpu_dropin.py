@@ -354,3 +354,55 @@ def test_group_functions_with_empty_cells():
         except ValueError:
             assert want_f.get("message") == "cannot convert float NaN to integer", name
     assert n_checked >= 20
+
+
+def test_batch_driver_writes_tiles_and_counters(tmp_path, capsys):
+    """python -m slamhip.run_logs on the three committed capture heads: one PNG per log holding exactly the tile
+    the batched pipeline renders, and a summary line with the reference's counters."""
+    from PIL import Image
+    from slamhip import run_logs
+    from slamhip.batch import process_texts
+    texts = []
+    for k in range(3):
+        z = np.load(os.path.join(GOLDEN, f"log{k}.npz"))
+        texts.append(z["text"].tobytes())
+        (tmp_path / f"cap{k}.txt").write_bytes(texts[-1])
+    out = tmp_path / "tiles"
+    assert run_logs.main([str(tmp_path), "--out-dir", str(out), "--tile", "256"]) == 0
+    lines = [json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    want = process_texts(texts, tile=256)
+    assert [os.path.basename(ln["log"]) for ln in lines] == ["cap0.txt", "cap1.txt", "cap2.txt"]
+    for k, (ln, r) in enumerate(zip(lines, want)):
+        z = np.load(os.path.join(GOLDEN, f"log{k}.npz"))
+        assert (ln["valid"], ln["discarded"]) == (int(z["valid"]), int(z["discarded"]))
+        assert ln["kept"] == len(r["kept"]["ue"]) and ln["grid"] == [len(r["aod"]), len(r["aoa"])]
+        img = np.asarray(Image.open(out / f"cap{k}_tile.png"))
+        assert img.shape == (256, 256, 4) and np.array_equal(img, r["tile"])
+    assert run_logs.main([str(tmp_path / "nothing_here.txt")]) == 1
+
+
+def test_batch_driver_two_ranks_gather_to_rank_zero(tmp_path):
+    """The driver under torch.distributed with two ranks (sharing this GPU; gloo collectives staged through the host):
+    files are balanced over the ranks and rank 0 writes every tile, the same bytes as the single-process run."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import PKG
+    from slamhip.batch import process_texts
+    texts = []
+    for k in range(3):
+        z = np.load(os.path.join(GOLDEN, f"log{k}.npz"))
+        texts.append(z["text"].tobytes())
+        (tmp_path / f"cap{k}.txt").write_bytes(texts[-1])
+    out = tmp_path / "tiles"
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", "-m", "slamhip.run_logs", str(tmp_path), "--out-dir", str(out), "--tile", "256",
+           "--backend", "gloo"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(os.path.basename(ln["log"]) for ln in lines) == ["cap0.txt", "cap1.txt", "cap2.txt"]
+    assert {ln["rank"] for ln in lines} == {0, 1}
+    for k, r in enumerate(process_texts(texts, tile=256)):
+        assert np.array_equal(np.asarray(Image.open(out / f"cap{k}_tile.png")), r["tile"])
