@@ -13,8 +13,12 @@
 
 namespace {
 
-constexpr int PIVOT_CHUNK = 65536;     // rows per workgroup of the pivot
-static_assert(PIVOT_CHUNK <= 65536 && PIVOT_CHUNK % 8192 == 0, "packed accumulators count up to 2^16 rows");
+// Entries per workgroup of the pivot, as a power of two.  A cell's accumulator packs the count (CHUNK_LOG2 + 1
+// bits at the top) over the sum, so the larger the chunk the smaller the values it can take: 2^16 entries leave
+// room for any non-negative int32, 2^18 for values below 2^27 (the capture format's RSS has 18 bits).  Values
+// outside the room bypass the accumulator.  Fewer, larger chunks mean fewer flushes of 4096 cells each.
+template <typename T32> struct pivot_chunk { static constexpr int log2 = 16; };
+template <> struct pivot_chunk<uint32_t> { static constexpr int log2 = 18; };
 constexpr int MAX_AXIS = 64;
 constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
 
@@ -33,9 +37,12 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
                                                 int n_axis, unsigned long long *gsum, uint32_t *gcnt,
                                                 const uint32_t *slot_cnt, uint32_t slot_stride)
 {
-    // One packed accumulator per cell: count in the top 17 bits, sum below (a chunk holds 2^16 rows of less
-    // than 2^31 each, so the sum stays under 2^47).  Rows are padded to 65 cells: consecutive BS beams at one
-    // UE beam are n_axis cells apart, which would put a whole wave on one LDS bank.
+    // One packed accumulator per cell: count at the top, sum below (see pivot_chunk).  Rows are padded to 65
+    // cells: consecutive BS beams at one UE beam are n_axis cells apart, which would put a whole wave on one LDS bank.
+    constexpr int CHUNK_LOG2 = pivot_chunk<T32>::log2, PIVOT_CHUNK = 1 << CHUNK_LOG2, SHIFT = 63 - CHUNK_LOG2;
+    constexpr int64_t ROW_LIMIT = 1ll << (SHIFT - CHUNK_LOG2);
+    constexpr int NH = 4;                  // groups of four entries per thread and step
+    static_assert(PIVOT_CHUNK % (4096 * NH) == 0, "a step covers 4096 * NH entries");
     constexpr int LSTRIDE = MAX_AXIS + 1;
     __shared__ unsigned long long acc[MAX_AXIS * LSTRIDE];
     __shared__ int8_t b2a[64];
@@ -50,13 +57,14 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
     const size_t fb = (size_t)f * row_cap;
     using V8 = typename v4<T8>::type;
     using V32 = typename v4<T32>::type;
-    // two groups of four entries per thread and step, loads first so both are in flight together
-    for (uint32_t base = r0 + tid * 4; base < r1; base += 8192) {
-        uint32_t lim[2];
-        V8 u[2], b[2];
-        V32 r[2];
+    // NH groups of four entries per thread and step, loads first so all are in flight together (the slotted
+    // layout leaves about a third of the lanes without rows, so each active one has to cover more latency)
+    for (uint32_t base = r0 + tid * 4; base < r1; base += 4096u * NH) {
+        uint32_t lim[NH];
+        V8 u[NH], b[NH];
+        V32 r[NH];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             const uint32_t i0 = base + 4096u * h;
             lim[h] = 0;
             if (i0 >= r1) continue;
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
             r[h] = *reinterpret_cast<const V32 *>(rss + fb + i0);
         }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NH; h++) {
             const uint32_t i0 = base + 4096u * h;
             if (i0 >= lim[h]) continue;
             const int64_t uu[4] = {(int64_t)u[h].x, (int64_t)u[h].y, (int64_t)u[h].z, (int64_t)u[h].w};
@@ -83,16 +91,21 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
                 if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
                 int c = b2a[uu[k]], rw = b2a[bb[k]];
                 if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
-                atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << 47));
+                if (rr[k] >= 0 && rr[k] < ROW_LIMIT) {
+                    atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << SHIFT));
+                } else {                                                             // no room in the packed sum
+                    atomicAdd(&gsum[(size_t)f * MAX_CELLS + rw * n_axis + c], (unsigned long long)rr[k]);
+                    atomicAdd(&gcnt[(size_t)f * MAX_CELLS + rw * n_axis + c], 1u);
+                }
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < n_axis * n_axis; i += 1024) {
         const unsigned long long a = acc[(i / n_axis) * LSTRIDE + (i % n_axis)];
-        if (a >> 47) {
-            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], a & ((1ull << 47) - 1));
-            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], (uint32_t)(a >> 47));
+        if (a >> SHIFT) {
+            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], a & ((1ull << SHIFT) - 1));
+            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], (uint32_t)(a >> SHIFT));
         }
     }
 }
@@ -403,7 +416,8 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
     if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
     SLAM_HIP(ctx, hipMemsetAsync(ws.sum, 0, (size_t)F * MAX_CELLS * 8, ctx->stream));
     SLAM_HIP(ctx, hipMemsetAsync(ws.cnt, 0, (size_t)F * MAX_CELLS * 4, ctx->stream));
-    dim3 grid((row_cap + PIVOT_CHUNK - 1) / PIVOT_CHUNK, F), block(1024);
+    constexpr uint32_t chunk = 1u << pivot_chunk<T32>::log2;
+    dim3 grid((row_cap + chunk - 1) / chunk, F), block(1024);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
                 rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt, slot_cnt, slot_stride);
     return SLAM_OK;

@@ -616,3 +616,37 @@ def test_skipped_token_lines_follow_the_reference(ops):
     raw = b"z " * 5000
     idx, beg, end = ops.token_rejects(raw)
     assert idx.tolist() == list(range(5000)) and beg.tolist() == list(range(0, 10000, 2)) and (end - beg == 1).all()
+
+
+def test_pivot_values_outside_the_packed_accumulators_room(ops, mapping):
+    """Sums stay exact for values the packed per-cell accumulators have no room for: negative and near-2^31 RSS on
+    the int32 entry point, RSS of 2^27 and above in the batched path's unsigned rows (rendered again from
+    overwritten kept rows)."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_ALL, STAGE_RENDER
+    rng = np.random.default_rng(31)
+    n = 200_000
+    ue, bs = rng.integers(0, 64, n), rng.integers(0, 64, n)
+    rss = rng.integers(-2 ** 31, 2 ** 31, n)
+    rss[::3] = rng.integers(15000, 93000, len(rss[::3]))
+    b2a, angles = ops.axis_from_mapping(mapping)
+    s, c, m = ops.pivot_mean(ue, bs, rss, b2a, len(angles))
+    mat, aod, aoa, so, co = O.pivot_mean(ue, bs, rss, mapping)
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+    # batched path: decode + correct a capture, then overwrite the kept RSS column and render again
+    z = np.load(os.path.join(GOLDEN, "log0.npz"))
+    text = torch.from_numpy(np.concatenate([z["text"], np.zeros(64, np.uint8)])).cuda()
+    pipe = FramePipeline(1, len(z["text"]), tile_w=64, tile_h=64, mapping=mapping)
+    pipe.set_layout([0], [len(z["text"])])
+    pipe.run(text, stages=STAGE_ALL)
+    torch.cuda.synchronize()
+    big = torch.from_numpy(rng.integers(0, 2 ** 32, pipe.k_rss.numel(), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
+    big[::2] &= 0x3FFFF                                   # half of them the capture format's 18 bits
+    pipe.k_rss.copy_(big)
+    pipe.run(text, stages=STAGE_RENDER)
+    k = pipe.frame_kept(0)
+    full = pipe.frame_matrix(0)[0]
+    mat, aod, aoa, so, co = O.pivot_mean(k["ue"], k["bs"], k["rss"].astype(np.int64), mapping)
+    want = np.where(co > 0, so / np.maximum(co, 1), np.nan)
+    assert int((k["rss"] >= 2 ** 27).sum()) > 100
+    assert np.array_equal(full, want, equal_nan=True)
