@@ -428,9 +428,9 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
                 const uint32_t *bbase = bits.nbase + (size_t)f * bits.stride;
                 const uint32_t mine = lane < ntile ? bbase[T0 + lane] : 0xFFFFFFFFu;
                 const uint32_t j = b0 + lane;
-                uint32_t owner = 0, obase = (uint32_t)__shfl((int)mine, 0, 64);
+                uint32_t owner = 0, obase = (uint32_t)__builtin_amdgcn_readlane((int)mine, 0);
                 for (uint32_t t = 1; t < ntile; t++) {            // last tile whose base is <= j
-                    const uint32_t bt = (uint32_t)__shfl((int)mine, (int)t, 64);
+                    const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)t);
                     if (bt <= j) { owner = t; obase = bt; }
                 }
                 if (lane < m) pay = bits.pay[((size_t)f * bits.stride + T0 + owner) * BL_PAY_CAP + (j - obase)];
@@ -450,21 +450,40 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
             phase_of(clk, prm, &q, &r);
             key = ((unsigned long long)r << 32) | lane;
         }
+        uint32_t ph, idx;
+        if ((uint32_t)prm.cycle < (1u << 26)) {
+            // phase and lane fit one dword: the network exchanges single registers
+            uint32_t k32 = lane < m ? (r << 6) | lane : 0xFFFFFFFFu;
 #pragma unroll
-        for (uint32_t k = 2; k <= 64; k <<= 1) {
+            for (uint32_t k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                const unsigned long long other = shfl64(key, (int)(lane ^ j));
-                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
-                key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ j) << 2), (int)k32);
+                    const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+                    k32 = take_min ? min(k32, other) : max(k32, other);
+                }
             }
+            ph = k32 >> 6;
+            idx = k32 & 63u;
+        } else {
+#pragma unroll
+            for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned long long other = shfl64(key, (int)(lane ^ j));
+                    const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+                    key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+                }
+            }
+            ph = (uint32_t)(key >> 32);
+            idx = (uint32_t)key;
         }
         // lane i now holds the i-th smallest (phase, index); the first of every phase is kept
-        const uint32_t ph = (uint32_t)(key >> 32), idx = (uint32_t)key;
         const uint32_t ph_left = (uint32_t)__shfl_up((int)ph, 1, 64);
         const bool keep = lane < m && (lane == 0 || ph_left != ph);
         const uint64_t km = __ballot(keep);
-        const uint32_t qi = (uint32_t)__shfl((int)q, (int)(idx & 63u), 64), bi = (uint32_t)__shfl((int)bsv, (int)(idx & 63u), 64);
+        const uint32_t ia = (idx & 63u) << 2;
+        const uint32_t qi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ia, (int)q), bi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ia, (int)bsv);
         if (keep) {
             const uint32_t o = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
             ws.srt_rb[bsb + b0 + o] = ph;
@@ -797,6 +816,13 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 // kept row goes straight to the front of its block's entries.
 constexpr int FIN_TPB = 3;            // consecutive blocks of entries one workgroup of k_rows_finish walks
 
+// v of the lane whose byte address (4 * lane, below 256) is given: a bare ds_bpermute, without the lane
+// arithmetic __shfl adds for sub-wave widths.
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane_byte_addr)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)lane_byte_addr, (int)v);
+}
+
 template <typename V, typename T>
 __device__ __forceinline__ void unpack4(const V &q, T v[4])
 {
@@ -906,6 +932,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                     }
                     // lower bound of every row's phase: the first three levels compare against seven entries held
                     // in scalar registers, the last four fetch one entry per row and step
+                    // positions are kept as lane byte addresses (4 * index), the unit ds_bpermute takes
                     uint32_t lo[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -914,54 +941,55 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                         const uint32_t m = a ? pv[5] : pv[1];                        // entry 47 : 15
                         const bool b = m < r;
                         const uint32_t q = a ? (b ? pv[6] : pv[4]) : (b ? pv[2] : pv[0]);   // entries 55, 39, 23, 7
-                        lo[k] = (a ? 32u : 0u) + (b ? 16u : 0u) + (q < r ? 8u : 0u);
+                        lo[k] = (a ? 128u : 0u) + (b ? 64u : 0u) + (q < r ? 32u : 0u);
                     }
 #pragma unroll
                     for (uint32_t h = 4; h; h >>= 1) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) lo[k] += (uint32_t)__shfl((int)t_r, (int)(lo[k] + h - 1), 64) < r1[k] ? h : 0u;
+                        for (int k = 0; k < 4; k++) lo[k] += lane_read(t_r, lo[k] + 4u * (h - 1)) < r1[k] ? 4u * h : 0u;
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) lo[k] += (uint32_t)__shfl((int)t_r, (int)lo[k], 64) < r1[k] ? 1u : 0u;
+                    for (int k = 0; k < 4; k++) lo[k] += lane_read(t_r, lo[k]) < r1[k] ? 4u : 0u;
                     if (prm.small_tol) {
                         // 0 <= 2*tol < cycle: a neighbour qualifies only through its short way round, so the forward
                         // distance to the successor and the backward distance to the predecessor (either may wrap past
                         // the cycle's end, which moves k by one) are the residuals; no absolute values, no halves.
+                        const uint32_t nd4 = 4u * nd, cyc = (uint32_t)prm.cycle;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const bool wrap_s = lo[k] >= nd, wrap_p = lo[k] == 0;
-                            const uint32_t is = wrap_s ? 0u : lo[k], ip = wrap_p ? nd - 1 : lo[k] - 1;
-                            const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
-                            const uint32_t cyc = (uint32_t)prm.cycle;
+                            const bool wrap_s = lo[k] >= nd4, wrap_p = lo[k] == 0;
+                            const uint32_t is = wrap_s ? 0u : lo[k], ip = wrap_p ? nd4 - 4u : lo[k] - 4u;
+                            const uint32_t vs = lane_read(t_r, is), vp = lane_read(t_r, ip);
                             const uint32_t rs_ = vs + (wrap_s ? cyc : 0u) - r1[k], rp_ = r1[k] + (wrap_p ? cyc : 0u) - vp;
                             bool pred = rp_ < rs_;
                             if (__any(rp_ == rs_)) {                                 // ties: the earlier baseline (rare)
-                                const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
+                                const uint32_t xs_ = lane_read(t_x, is), xp_ = lane_read(t_x, ip);
                                 pred = pred || (rp_ == rs_ && xp_ < xs_);
                             }
                             const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_;
-                            const int32_t adj = pred ? (wrap_p ? -1 : 0) : (wrap_s ? 1 : 0);
-                            const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
+                            const uint32_t adj = pred ? (wrap_p ? 0xFFFFFFFFu : 0u) : (wrap_s ? 1u : 0u);
+                            const uint32_t wq = lane_read(t_y, w), wb = lane_read(t_z, w);
                             if (fl[k] == 1 || gi[k] != gg || resid > (uint32_t)prm.tol) continue;
-                            res[k] = (int32_t)((wb + (q1[k] - wq) + (uint32_t)adj) & (uint32_t)(prm.mod_base - 1));
+                            res[k] = (int32_t)((wb + (q1[k] - wq) + adj) & (uint32_t)(prm.mod_base - 1));
                             keep |= 1u << k;
                         }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             // all lanes take part in the permutes; rows of other groups drop the result
-                            const uint32_t is = lo[k] < nd ? lo[k] : 0, ip = lo[k] > 0 ? lo[k] - 1 : nd - 1;
-                            const uint32_t vs = (uint32_t)__shfl((int)t_r, (int)is, 64), vp = (uint32_t)__shfl((int)t_r, (int)ip, 64);
+                            const uint32_t li = lo[k] >> 2;
+                            const uint32_t is = li < nd ? li : 0, ip = li > 0 ? li - 1 : nd - 1;
+                            const uint32_t vs = lane_read(t_r, 4u * is), vp = lane_read(t_r, 4u * ip);
                             const uint32_t cyc = (uint32_t)prm.cycle;
                             const uint32_t ds_ = vs > r1[k] ? vs - r1[k] : r1[k] - vs, dp_ = vp > r1[k] ? vp - r1[k] : r1[k] - vp;
                             const uint32_t rs_ = min(ds_, cyc - ds_), rp_ = min(dp_, cyc - dp_);
                             bool pred = rp_ < rs_;
                             if (__any(rp_ == rs_)) {                                     // ties: the earlier baseline (rare)
-                                const uint32_t xs_ = (uint32_t)__shfl((int)t_x, (int)is, 64), xp_ = (uint32_t)__shfl((int)t_x, (int)ip, 64);
+                                const uint32_t xs_ = lane_read(t_x, 4u * is), xp_ = lane_read(t_x, 4u * ip);
                                 pred = pred || (rp_ == rs_ && xp_ < xs_);
                             }
                             const uint32_t w = pred ? ip : is, resid = pred ? rp_ : rs_, vw = pred ? vp : vs;
-                            const uint32_t wq = (uint32_t)__shfl((int)t_y, (int)w, 64), wb = (uint32_t)__shfl((int)t_z, (int)w, 64);
+                            const uint32_t wq = lane_read(t_y, 4u * w), wb = lane_read(t_z, 4u * w);
                             if (fl[k] == 1 || gi[k] != gg || (int64_t)resid > (int64_t)prm.tol) continue;
                             res[k] = round_to_beam(q1[k], r1[k], wq, vw, wb, prm);
                             keep |= 1u << k;
