@@ -406,3 +406,52 @@ def test_batch_driver_two_ranks_gather_to_rank_zero(tmp_path):
     assert {ln["rank"] for ln in lines} == {0, 1}
     for k, r in enumerate(process_texts(texts, tile=256)):
         assert np.array_equal(np.asarray(Image.open(out / f"cap{k}_tile.png")), r["tile"])
+
+
+def test_batch_beyond_4_gib_arrays_matches_small_batches():
+    """A batch larger than the benchmark's (1100 frames of 256 x 4096: 38 GB of text, more than 2^32 bytes in every
+    dword row array): frames
+    from the front, the middle and the end of the batch give the same rows, kept rows, matrix, tile and counters as
+    when they are processed in a batch of their own, and one of them is checked against the oracle."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+    B, N, F = 256, 4096, 1100
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=1000)
+    mapping, lut = default_mapping(), viridis_lut()
+    big = FramePipeline(F, tl, tile_w=256, tile_h=256, mapping=mapping, lut=lut)
+    big.set_uniform_layout(F, stride, tl)
+    big.run(text)
+    st = big.stats_host()
+    assert int(st[:, 1].sum()) == 0 and int(st[:, 15].sum()) == 0          # strict text, single pass everywhere
+    assert big.row_cap * F * 4 > 2 ** 32
+    pick = [0, 1, 549, 550, 1098, 1099]
+    small = FramePipeline(len(pick), tl, tile_w=256, tile_h=256, mapping=mapping, lut=lut)
+    small.set_layout([f * stride for f in pick], [tl] * len(pick))
+    small.run(text)
+    ss = small.stats_host()
+    for j, f in enumerate(pick):
+        assert np.array_equal(st[f], ss[j]), f
+        ra, rb = big.frame_rows(f, st), small.frame_rows(j, ss)
+        ka, kb = big.frame_kept(f, st), small.frame_kept(j, ss)
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), (f, k)
+        for k in ka:
+            assert np.array_equal(ka[k], kb[k]), (f, k)
+        ma, mb = big.frame_matrix(f, st), small.frame_matrix(j, ss)
+        assert np.array_equal(ma[0], mb[0], equal_nan=True) and np.array_equal(ma[1], mb[1], equal_nan=True)
+        assert np.array_equal(big.frame_tile(f), small.frame_tile(j))
+    # every frame of the batch: counters as the generator implies (all records of a frame are valid but the
+    # tag-flipped ones; 256 groups), and no two frames alike
+    assert (st[:, 4] == B).all() and (st[:, 2] > B * N * 0.99).all() and (st[:, 2] < B * N).all()
+    assert len({(int(a), int(b), int(c)) for a, b, c in st[:, [2, 3, 6]]}) > F // 2
+    f = F - 1
+    t = text[f * stride:f * stride + tl].cpu().numpy()
+    rows_o, v, d = O.parse_groups(O.read_bytes(t.tobytes()))
+    kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+    assert (int(st[f, 2]), int(st[f, 3]), int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (v, d, ng, nb, len(kept_o["ue"]))
+    kept = big.frame_kept(f, st)
+    for k in kept_o:
+        assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
