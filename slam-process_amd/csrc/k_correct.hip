@@ -399,12 +399,26 @@ __device__ __forceinline__ unsigned long long baseline_from_tiles(const tile_bit
 }
 
 constexpr uint32_t WAVE_SORT_MAX = 64;      // groups of up to this many baselines are sorted by one wave in registers
+constexpr uint32_t MID_SORT_MAX = 256;      // ... and up to this many by one wave in its own piece of LDS
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware runs a wave's LDS
+// operations in order, so only the compiler has to be told not to move them across this point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Groups with at most 64 baselines, one wave per group: bitonic sort of (phase, index) across the lanes with lane
-// exchanges, no LDS and no barriers.  Same outputs as k_bl_sort, which skips these groups when told so.
+// exchanges, no LDS and no barriers.  Groups of 65 .. 256 baselines: still one wave per group, the network runs
+// over the wave's own piece of LDS (two or four elements per lane and stage), again without block barriers.
+// Same outputs as k_bl_sort, which skips these groups when told so.
 __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t row_cap, correct_params prm,
                                                         const uint32_t *stats, tile_bits bits)
 {
+    __shared__ unsigned long long mid_keys[4][MID_SORT_MAX];
+    __shared__ uint32_t mid_q[4][MID_SORT_MAX], mid_bs[4][MID_SORT_MAX];
     const uint32_t f = blockIdx.y, lane = lane_id();
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
     const size_t gs = (size_t)f * (row_cap + 1);
@@ -415,7 +429,66 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
             if (lane == 0) ws.grp_nd[gs + g] = 0;
             continue;
         }
-        if (m > WAVE_SORT_MAX) continue;
+        if (m > MID_SORT_MAX) continue;
+        if (m > WAVE_SORT_MAX) {
+            unsigned long long *kk = mid_keys[threadIdx.x >> 6];
+            uint32_t *sq = mid_q[threadIdx.x >> 6], *sb = mid_bs[threadIdx.x >> 6];
+            const uint32_t P = m <= 128 ? 128u : 256u;
+            uint32_t T0 = 0, T1 = 0;
+            if (bits.pay) { T0 = ws.grp_row[gs + g] / SLOT_ROWS; T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS; }
+            for (uint32_t i = lane; i < P; i += 64) {
+                unsigned long long key = ~0ull;
+                if (i < m) {
+                    int32_t clk;
+                    uint32_t bsv, q, r;
+                    if (bits.pay) {
+                        const unsigned long long p = baseline_from_tiles(bits, f, b0 + i, T0, T1);
+                        clk = (int32_t)(uint32_t)p;
+                        bsv = (uint32_t)((p >> 32) & 0xFFu);
+                    } else {
+                        clk = ws.bl_clk[bsb + b0 + i];
+                        bsv = (uint32_t)ws.bl_bs[bsb + b0 + i];
+                    }
+                    phase_of(clk, prm, &q, &r);
+                    key = ((unsigned long long)r << 32) | i;
+                    sq[i] = q;
+                    sb[i] = bsv;
+                }
+                kk[i] = key;
+            }
+            wave_lds_fence();
+            for (uint32_t k = 2; k <= P; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t p = lane; p < P / 2; p += 64) {         // pair p: element i and its partner i | j
+                        const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                        const unsigned long long a = kk[i], b = kk[l];
+                        if ((a > b) == ((i & k) == 0)) { kk[i] = b; kk[l] = a; }
+                    }
+                    wave_lds_fence();
+                }
+            }
+            uint32_t run = 0;                                  // distinct phases written so far
+            for (uint32_t seg = 0; seg < P; seg += 64) {
+                const uint32_t i = seg + lane;
+                bool keep = false;
+                unsigned long long key = 0;
+                if (i < m) {
+                    key = kk[i];
+                    keep = (i == 0) || ((uint32_t)(kk[i - 1] >> 32) != (uint32_t)(key >> 32));
+                }
+                const uint64_t km = __ballot(keep);
+                if (keep) {
+                    const uint32_t o = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                    const uint32_t idx = (uint32_t)key;
+                    ws.srt_rb[bsb + b0 + o] = (uint32_t)(key >> 32);
+                    ws.srt_pay[bsb + b0 + o] = make_uint4(idx, sq[idx], sb[idx], 0);
+                }
+                run += (uint32_t)__popcll(km);
+            }
+            if (lane == 0) ws.grp_nd[gs + g] = run;
+            wave_lds_fence();                                  // the next group reuses the wave's piece of LDS
+            continue;
+        }
         uint32_t q = 0, r = 0, bsv = 0;
         unsigned long long key = ~0ull;
         unsigned long long pay = 0;
@@ -1173,7 +1246,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), w2, in.row_cap, prm,
                     stats, in.bits);
         SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), w2, in.row_cap, prm, stats,
-                    in.bits, WAVE_SORT_MAX);
+                    in.bits, MID_SORT_MAX);
         SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
                     rt_max, ws.rt_nbound, w2, prm_k, out, stats);
         return SLAM_OK;
@@ -1188,7 +1261,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), ws, in.row_cap, prm, stats,
                 tile_bits());
     SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), ws, in.row_cap, prm, stats,
-                tile_bits(), WAVE_SORT_MAX);
+                tile_bits(), MID_SORT_MAX);
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");

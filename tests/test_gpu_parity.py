@@ -179,6 +179,32 @@ def test_correct_large_group_rank_path(ops):
         assert np.array_equal(a.astype(np.int64), kept_o[k]), k
 
 
+@pytest.mark.parametrize("cyc", [61000, 97])
+def test_correct_mid_sized_groups(ops, cyc):
+    """Groups of 65 .. 256 baselines on the int32 entry point (one wave sorts each in LDS); the short cycle makes most
+    phases repeat, so the earliest-baseline rule decides."""
+    rng = np.random.default_rng(cyc)
+    cols = []
+    for m in (65, 66, 127, 128, 129, 200, 255, 256, 257, 64):
+        n = 6 * m
+        flag = np.zeros(n, np.int64)
+        rss = rng.integers(15000, 93000, n)
+        at = np.sort(rng.choice(np.arange(1, n), m, replace=False))
+        at = at[np.concatenate(([True], np.diff(at) > 1))]            # a baseline needs a FLAG=0 row before it
+        flag[at] = 1
+        rss[at] = rss[at - 1]
+        clk = np.cumsum(rng.integers(0, 3 * cyc, n)) % (2 ** 30 - 1)
+        cols.append(np.stack([flag, np.arange(n) * 64 // n, rng.integers(0, 64, n), rss, clk], 1))
+    t = np.concatenate(cols)
+    kept_o, ng, nb = O.filter_corrected(t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4], cyc, min(500, cyc // 3), 64)
+    c = ops.correct(t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4], cyc, min(500, cyc // 3), 64)
+    assert c["n_groups"] == ng == 10 and len(c["baselines"][0]) == nb
+    counts = np.bincount(c["baselines"][2], minlength=10)
+    assert counts.max() > 200 and ((counts > 64) & (counts <= 256)).sum() >= 6
+    for a, k in zip(c["kept"], ["ue", "bs", "rss", "clk"]):
+        assert np.array_equal(a.astype(np.int64), kept_o[k]), k
+
+
 def test_explicit_baselines(ops):
     rows = np.array([[0, 0, 10, 21, 2_000_000], [1, 1, 12, 21, 2_000_050], [0, 2, 99, 21, 2_061_020],
                      [0, 1, 99, 21, 2_061_510]], np.int64)
@@ -496,10 +522,10 @@ def test_batched_correction_wraps_and_tolerances(mapping, lut, cycle, tol):
             assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
 
 
-@pytest.mark.parametrize("n_baselines", [300, 1500, 2600])
+@pytest.mark.parametrize("n_baselines", [65, 100, 128, 129, 256, 257, 300, 1500, 2600])
 def test_batched_correction_large_groups(mapping, lut, n_baselines):
-    """Groups with more baselines than a wave holds: LDS tables (<= 1023 phases), tables searched in global memory,
-    the block bitonic sort (<= 2048 baselines) and the rank sort above it."""
+    """Groups with more baselines than a wave's registers hold: the wave-level LDS sort (<= 256), LDS tables (<= 1023
+    phases), tables searched in global memory, the block bitonic sort (<= 2048 baselines) and the rank sort above it."""
     import torch
     from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
     cycle, tol = 61000, 500
