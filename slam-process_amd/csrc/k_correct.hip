@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void k_tile_groups(rows_in_t<T8, T32> in, corr
     const uint32_t nt = n / SLOT_ROWS;
     const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
     const size_t fb = (size_t)f * in.row_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws.rt_nbase[f] = 0;              // "frame has a large group", set by the sort
     const uint32_t *nb = in.bits.nbound + (size_t)f * in.bits.stride;       // exclusive bases after the scan
     const uint32_t *nl = in.bits.nbase + (size_t)f * in.bits.stride;
     bool work = false;
@@ -429,6 +430,9 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
             if (lane == 0) ws.grp_nd[gs + g] = 0;
             continue;
         }
+        // in the batched path rt_nbase is free: its entry f tells k_rows_finish that frame f has a group whose phase
+        // table may not fit a wave's registers (bit 0) and k_bl_sort that one is left for it to sort (bit 2)
+        if (m > WAVE_SORT_MAX && bits.pay && lane == 0) atomicOr(ws.rt_nbase + f, m > MID_SORT_MAX ? 5u : 1u);
         if (m > MID_SORT_MAX) continue;
         if (m > WAVE_SORT_MAX) {
             unsigned long long *kk = mid_keys[threadIdx.x >> 6];
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.y, tid = threadIdx.x;
+    if (bits.pay && skip_upto >= MID_SORT_MAX && !(ws.rt_nbase[f] & 4u)) return;    // k_bl_sort_small saw no group for this kernel
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
     const size_t gs = (size_t)f * (row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
@@ -902,21 +907,33 @@ __device__ __forceinline__ void unpack4(const V &q, T v[4])
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
 
-template <typename T8, typename T32>
+//
+// Two builds of one body.  LEAN holds only the common case -- every phase table of the frame fits a wave's registers
+// (no group above 64 baselines: bit 0 of the frame's flags clear), the tolerance is below half a cycle, the workgroup
+// touches fewer than TAB_MAX_GROUPS groups -- which keeps it at 80 VGPRs and 10 KiB of LDS, six waves per SIMD.  It
+// leaves a frame with a large group alone; a workgroup spanning too many groups sets its flag in `defer` (and bit 1 of
+// the frame's flags) and leaves.  The full build has every path; given `defer` it serves only those frames and
+// workgroups, and where a frame's flags are zero -- the usual case -- its workgroups leave after one load.
+template <typename T8, typename T32, bool LEAN>
 __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint32_t rt_max, const uint32_t *rt_gbase,
                                                       correct_ws ws, correct_params prm, kept_out_t<T8, T32> out,
-                                                      uint32_t *stats)
+                                                      uint32_t *stats, uint32_t *defer, uint32_t *frame_flags)
 {
     using V8 = typename vec4_of<T8>::type;
     using V32 = typename vec4_of<T32>::type;
     __shared__ uint32_t sh[17];
-    __shared__ uint32_t t_rb[TAB_CAP];
-    __shared__ uint4 t_pay[TAB_CAP];
+    __shared__ uint32_t t_rb[LEAN ? 1 : TAB_CAP];
+    __shared__ uint4 t_pay[LEAN ? 1 : TAB_CAP];
     __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
     __shared__ uint32_t wave_tot[2][4];                   // kept rows per wave, double-buffered over the blocks walked
     __shared__ __attribute__((aligned(16))) T32 k_rs[ROWS_PER_BLOCK], k_ck[ROWS_PER_BLOCK];   // kept rows of a block, packed
     __shared__ __attribute__((aligned(16))) T8 k_ue[ROWS_PER_BLOCK], k_bs[ROWS_PER_BLOCK];
-    const uint32_t f = blockIdx.y, tile0 = blockIdx.x * FIN_TPB, tid = threadIdx.x;
+    const uint32_t f = blockIdx.y, bx = blockIdx.x, tile0 = bx * FIN_TPB, tid = threadIdx.x;
+    if (defer) {
+        const uint32_t ff = frame_flags[f];              // bit 0: a group above 64 baselines; bit 1: a workgroup deferred
+        if (LEAN ? (ff & 1u) != 0 : ff == 0) return;
+        if (!LEAN && !(ff & 1u) && !defer[(size_t)f * rt_max + bx]) return;
+    }
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     if (tile0 * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
@@ -950,6 +967,13 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         g_bl[tid] = ws.grp_bl[gs + glo_all + tid];
     }
     __syncthreads();
+    if (LEAN) {
+        if (tid == 0) {
+            defer[(size_t)f * rt_max + bx] = staged ? 0u : 1u;
+            if (!staged) atomicOr(frame_flags + f, 2u);
+        }
+        if (!staged) return;
+    }
     uint32_t in_lds_group = 0xFFFFFFFFu, P = 2;          // group whose table sits in t_rb / t_pay, its padded length
     uint32_t in_reg_group = 0xFFFFFFFFu, t_r = 0xFFFFFFFFu, t_x = 0, t_y = 0, t_z = 0;   // small table: entry `lane`
     uint32_t pv[7] = {0, 0, 0, 0, 0, 0, 0};              // its entries 7, 15, ..., 55 (wave-uniform)
@@ -982,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
             }
         }
         uint32_t keep = 0;
-        if (staged) {
+        if (LEAN || staged) {
             for (uint32_t gg = glo; gg <= ghi; gg++) {
                 const uint32_t nd = g_nd[gg - glo_all];
                 if (nd == 0) continue;                              // block-uniform
@@ -1023,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) lo[k] += lane_read(t_r, lo[k]) < r1[k] ? 4u : 0u;
-                    if (prm.small_tol) {
+                    if (LEAN || prm.small_tol) {
                         // 0 <= 2*tol < cycle: a neighbour qualifies only through its short way round, so the forward
                         // distance to the successor and the backward distance to the predecessor (either may wrap past
                         // the cycle's end, which moves k by one) are the residuals; no absolute values, no halves.
@@ -1068,6 +1092,8 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                             keep |= 1u << k;
                         }
                     }
+                } else if (LEAN) {
+                    // not reached: such a workgroup has deferred
                 } else if (nd < TAB_CAP) {
                     if (in_lds_group != gg) {                       // consecutive blocks mostly stay in one group
                         __syncthreads();
@@ -1247,8 +1273,14 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                     stats, in.bits);
         SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), w2, in.row_cap, prm, stats,
                     in.bits, MID_SORT_MAX);
-        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
-                    rt_max, ws.rt_nbound, w2, prm_k, out, stats);
+        // the lean build first; what it defers (large groups, a tolerance of half a cycle or more) goes to the full one
+        uint32_t *defer = prm_k.small_tol ? ws.rt_nkept : nullptr;
+        const uint32_t wgs = (rt_max + FIN_TPB - 1) / FIN_TPB;
+        if (defer)
+            SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32, true>), dim3(wgs, F), block, in, rt_max, ws.rt_nbound,
+                        w2, prm_k, out, stats, defer, ws.rt_nbase);
+        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, false>), dim3(wgs, F), block,
+                    in, rt_max, ws.rt_nbound, w2, prm_k, out, stats, defer, ws.rt_nbase);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
@@ -1265,8 +1297,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
-        SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block, in,
-                    rt_max, ws.rt_nbound, ws, prm_k, out, stats);
+        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, false>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block,
+                    in, rt_max, ws.rt_nbound, ws, prm_k, out, stats, (uint32_t *)nullptr, (uint32_t *)nullptr);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, ws.rt_nbound, ws,
