@@ -236,8 +236,7 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
                                                        double *matrix, double *blurred, uint32_t *stats)
 {
     __shared__ double cm[MAX_CELLS];
-    __shared__ double bm[MAX_CELLS];
-    __shared__ double red[2048];
+    __shared__ double bm[MAX_CELLS];              // 64 KiB for the two grids: two workgroups fit a CU's LDS
     __shared__ double ang_r[MAX_AXIS], ang_c[MAX_AXIS], edge[MAX_AXIS + 1];
     __shared__ uint32_t rowp[MAX_AXIS], colp[MAX_AXIS];
     __shared__ int ridx[MAX_AXIS], cidx[MAX_AXIS];
@@ -286,7 +285,8 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
     if (blurred)
         for (int c = tid; c < h * w; c += 1024) blurred[(size_t)f * na * na + c] = fin[c];
     double mn, mx;
-    const bool any = block_minmax(fin, h * w, red, &mn, &mx);
+    __syncthreads();
+    const bool any = block_minmax(fin, h * w, fin == cm ? bm : cm, &mn, &mx);     // the grid not in use is the scratch
     uint8_t *cells = ws.cells + (size_t)f * MAX_CELLS * 4;
     if (!any) {
         if (tid == 0) st[SLAM_STAT_ALLNAN] = 1;
