@@ -65,10 +65,13 @@ def validate_beam_id(beam: int) -> bool:
 
 def _read_sheets(path: str, sheet_name: Optional[str], what: str):
     """One DataFrame when a sheet is named, else {sheet: DataFrame} like pd.read_excel(sheet_name=None)."""
+    def frame(table):          # an empty cell is NaN, as pd.read_excel gives it, also in a column that holds text
+        return pd.DataFrame({k: [np.nan if v is None else v for v in col] for k, col in table.items()})
+
     try:
         if sheet_name is not None:
-            return pd.DataFrame(xlsx.read_table(path, sheet_name))
-        return {n: pd.DataFrame(t) for n, t in xlsx.read_all_tables(path).items()}
+            return frame(xlsx.read_table(path, sheet_name))
+        return {n: frame(t) for n, t in xlsx.read_all_tables(path).items()}
     except Exception as e:
         raise RuntimeError(f"读取{what}Excel失败: {e}")
 
@@ -129,7 +132,11 @@ def read_main_data(input_path: str, ue_col: str = "UE_Beam", bs_col: str = "BS_B
     before = len(df)
     df = df.dropna(subset=["ue_beam", "bs_beam", "rss"] + (["flag"] if "flag" in df.columns else []))
     after_dropna = len(df)
-    ok = df["ue_beam"].between(0, 63) & df["bs_beam"].between(0, 63)
+    # validate_beam_id accepts integers only: a beam column that held an empty or non-numeric cell has become a
+    # float column, and then none of its rows passes (reference :166-168)
+    ok = pd.Series(True, index=df.index)
+    for c in ("ue_beam", "bs_beam"):
+        ok &= df[c].between(0, 63) if df[c].dtype.kind in "iu" else False
     if "flag" in df.columns:
         ok &= df["flag"] == 1
     df = df[ok]

@@ -211,3 +211,36 @@ dist.destroy_process_group()
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "ok").exists()
+
+
+def test_heatmap_reader_cleaning_rules(tmp_path):
+    """read_main_data's cleaning (excel_heatmap_v3.py:139-182), host-only: rows with a bad RSS cell go; beams outside
+    0..63 go; FLAG filters only when asked; a beam column with an empty or non-numeric cell turns float and then fails
+    validate_beam_id (integers only) on every row, so the table comes out empty and the function raises."""
+    import importlib.util
+    import matplotlib
+    matplotlib.use("Agg")
+    from slamhip import xlsx
+    spec = importlib.util.spec_from_file_location("mine_excel_heatmap_v3_clean", os.path.join(PKG, "excel_heatmap_v3.py"))
+    E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E)
+    hdr = ["UE_Beam", "BS_Beam", "RSS值", "FLAG"]
+    p = str(tmp_path / "a.xlsx")
+    xlsx.write_table(p, hdr, [[1, 2, 64, 3, -1, 5], [7, 8, 9, 10, 11, 63], [100, "x", 300, None, 500, 600.5], [1, 0, 1, 1, 1, 1]])
+    df = E.read_main_data(p)
+    assert df[["ue_beam", "bs_beam"]].to_numpy().tolist() == [[1, 7], [5, 63]] and df["rss"].tolist() == [100.0, 600.5]
+    assert df["ue_beam"].dtype.kind == "i"
+    df = E.read_main_data(p, flag_col="FLAG")
+    assert df[["ue_beam", "bs_beam", "flag"]].to_numpy().tolist() == [[1, 7, 1], [5, 63, 1]]
+    q = str(tmp_path / "b.xlsx")
+    xlsx.write_table(q, hdr, [[1, None, 3], [7, 8, 9], [100, 200, 300], [1, 1, 1]])
+    with pytest.raises(ValueError, match="清洗后主数据为空"):
+        E.read_main_data(q)
+    r = str(tmp_path / "c.xlsx")
+    xlsx.write_table(r, hdr, [[1, 2, 3], [7, "beam", 9], [100, 200, 300], [1, 1, 1]])
+    with pytest.raises(ValueError, match="清洗后主数据为空"):
+        E.read_main_data(r)
+    m = str(tmp_path / "m.xlsx")
+    xlsx.write_table(m, ["BeamID", "Angle"], [[0, 1, 64, -1, None, 2], [-10.0, None, 5.0, 6.0, 7.0, "30"]])
+    mp = E.read_mapping(m)
+    assert set(mp) == {0, 1, 2} and mp[0] == -10.0 and np.isnan(mp[1]) and mp[2] == 30.0
