@@ -126,6 +126,22 @@ def main():
     stride = ((tl + 255) // 256) * 256
     n_distinct = max(F, min(a.distinct_frames, (K + W) * F))
     n_distinct = (n_distinct // F) * F
+    # fit the batch to the memory that is free: text ring + per frame about 2.5 x its text (row arrays, kept rows,
+    # library workspace; 89 MB measured for a 34.6 MB frame) + its tile slots
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    per_frame = 2.5 * stride + a.tile * a.tile * 4 * (2 if (world > 1 and a.gather == "tiles") else 1) + (1 << 20)
+    need = n_distinct * stride + F * per_frame
+    if need > 0.92 * free_b:
+        scale = 0.92 * free_b / need
+        F = max(8, int(F * scale) // 8 * 8)
+        n_distinct = min(n_distinct, 2 * F) // F * F
+        print(f"bench: {free_b / 2**30:.0f} GiB free, batch reduced to {F} frames/step ({n_distinct} resident)", file=sys.stderr)
+    if world > 1:                                            # every rank runs the same batch size
+        ft = torch.tensor([F], dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+        if int(ft.item()) != F:
+            F = int(ft.item())
+            n_distinct = min(n_distinct, 2 * F) // F * F
     # frames of this rank: ids rank*n_distinct .. so every rank works on different data
     text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=local)
     gmode = "none" if (world == 1 or a.no_gather) else a.gather
