@@ -34,6 +34,8 @@ extern "C" {
 #define SLAM_E_CAPACITY     -3   /* an output buffer is too small; required size is reported */
 #define SLAM_E_EMPTY        -4   /* the stage produced no rows (the reference raises ValueError) */
 #define SLAM_E_ALLNAN       -5   /* matrix has no finite cell (excel_heatmap_v3.py:405-406) */
+#define SLAM_E_LIMITS       -7   /* log scale with a limit at or below the data minimum: the reference's LogNorm
+                                    (excel_heatmap_v3.py:413-418) fails with "Invalid vmin or vmax" */
 #define SLAM_E_RANGE        -6   /* a value does not fit the device representation */
 
 typedef struct slam_ctx slam_ctx;
@@ -129,8 +131,10 @@ int slam_blur_nan(slam_ctx *ctx, const double *in, int h, int w, double sigma, d
  * Replaces the data path of generate_heatmap (:396-456) after the blur: finite min/max,
  * Normalize / shifted LogNorm, 256-entry colormap lookup, and the pcolormesh of flat cells with
  * edges at midpoints (_edges :430-440), sampled into a data-only W x H RGBA tile (row 0 = largest
- * AoD).  vmin/vmax: NaN = autoscale.  Outputs (any may be NULL): cells_rgba [h*w*4],
- * tile_rgba [H*W*4], vmin_vmax_out[2] the limits used (after the log shift when use_log). */
+ * AoD).  vmin/vmax (NaN = none given) count on the log scale only: the reference hands the linear mesh neither a
+ * norm nor limits (:420-423, :449-456), so its linear scale always spans the finite data.  Empty and reversed
+ * intervals come out as matplotlib's colour bar leaves them (expanded by a tenth).  Outputs (any may be NULL):
+ * cells_rgba [h*w*4], tile_rgba [H*W*4], vmin_vmax_out[2] the limits used (after the log shift when use_log). */
 int slam_render(slam_ctx *ctx, const double *mat, int h, int w,
                 const double *aod, const double *aoa, int use_log, double vmin, double vmax,
                 const uint8_t *lut256x3, uint8_t *cells_rgba, uint8_t *tile_rgba, int W, int H,
@@ -155,7 +159,7 @@ typedef struct slam_batch {
     int32_t n_axis;
     double blur_sigma;            /* --blur-sigma, default 1.0 (excel_heatmap_v3.py:601-603)      */
     int32_t use_log;              /* --logscale                                                   */
-    double vmin, vmax;            /* NaN = autoscale                                              */
+    double vmin, vmax;            /* NaN = none given; used on the log scale only (see slam_render) */
     const uint8_t *lut_dev;       /* [256*3]                                                      */
     int32_t tile_w, tile_h;
     /* outputs; row arrays have row_cap entries per frame, frame f at offset f*row_cap (16-byte aligned
@@ -202,7 +206,7 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 #define SLAM_STAT_KEPT        6
 #define SLAM_STAT_N_AOD       7   /* rows of the compact matrix                                   */
 #define SLAM_STAT_N_AOA       8   /* cols of the compact matrix                                   */
-#define SLAM_STAT_ALLNAN      9   /* 1 = no finite cell, tile left transparent                    */
+#define SLAM_STAT_ALLNAN      9   /* 1 = no finite cell, 2 = invalid log-scale limits; tile left transparent */
 #define SLAM_STAT_VMIN_LO    10   /* vmin/vmax used, as two u32 halves of an f64 each             */
 #define SLAM_STAT_VMIN_HI    11
 #define SLAM_STAT_VMAX_LO    12

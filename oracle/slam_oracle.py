@@ -388,11 +388,26 @@ def edges(vals: Sequence[float]) -> np.ndarray:
     return e
 
 
-def normalise(mat: np.ndarray, use_log: bool, vmin: Optional[float], vmax: Optional[float]):
-    """Returns (norm in [0,1] or NaN, vmin_used, vmax_used) as the figure's colour scale does.
+def nonsingular_limits(lo: float, hi: float) -> Tuple[float, float]:
+    """What the colour bar's pass through matplotlib's nonsingular(expander=0.1) leaves of the norm's limits
+    (the figure has a colour bar, :457): an empty interval grows by a tenth of each end (to +-0.1 around zero),
+    reversed limits come out as (0.9 * smaller, larger)."""
+    if hi < lo:
+        return hi - 0.1 * abs(hi), lo
+    big = max(abs(lo), abs(hi))
+    if big < 2.2250738585072014e-287:
+        return -0.1, 0.1
+    if hi - lo <= big * 1e-15:
+        return lo - 0.1 * abs(lo), hi + 0.1 * abs(hi)
+    return lo, hi
 
-    Linear (:420-423): Normalize autoscaled to the finite min/max.
-    Log (:409-419): shifted = mat - min + 1e-6, LogNorm between the (shifted) limits.
+
+def normalise(mat: np.ndarray, use_log: bool, vmin: Optional[float], vmax: Optional[float]):
+    """Returns (norm or NaN, vmin_used, vmax_used) as the figure's colour scale does.
+
+    Linear (:420-423, :449-456): the mesh gets neither a norm nor limits, so vmin / vmax play no part and the
+    scale is autoscaled to the finite min/max.  Log (:409-419): shifted = mat - min + 1e-6, LogNorm between the
+    limits shifted alike; a limit that is not positive after the shift fails like LogNorm does.
     """
     mat = np.asarray(mat, np.float64)
     fin = np.isfinite(mat)
@@ -403,17 +418,16 @@ def normalise(mat: np.ndarray, use_log: bool, vmin: Optional[float], vmax: Optio
         sh = mat - mn + 1e-6
         lo = (vmin - mn + 1e-6) if vmin is not None else sh[fin].min()
         hi = (vmax - mn + 1e-6) if vmax is not None else sh[fin].max()
+        if not (lo > 0 and hi > 0 and math.isfinite(lo) and math.isfinite(hi)):
+            raise ValueError("Invalid vmin or vmax")
+        lo, hi = nonsingular_limits(float(lo), float(hi))
         with np.errstate(invalid="ignore", divide="ignore"):
             t = np.log10(sh)
         tlo, thi = math.log10(lo), math.log10(hi)
-        nrm = (t - tlo) / (thi - tlo) if thi != tlo else np.zeros_like(t)
+        nrm = (t - tlo) / (thi - tlo)
         return np.where(fin, nrm, np.nan), float(lo), float(hi)
-    lo = float(vmin) if vmin is not None else float(mat[fin].min())
-    hi = float(vmax) if vmax is not None else float(mat[fin].max())
-    if hi == lo:
-        nrm = np.zeros_like(mat)
-    else:
-        nrm = (mat - lo) / (hi - lo)
+    lo, hi = nonsingular_limits(float(mat[fin].min()), float(mat[fin].max()))
+    nrm = (mat - lo) / (hi - lo)
     return np.where(fin, nrm, np.nan), lo, hi
 
 

@@ -641,6 +641,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
                          (uint32_t *)(b + ost)));
     uint32_t st[SLAM_STAT_WORDS];
     SLAM_TRY(read_stats(ctx, (uint32_t *)(b + ost), st));
+    if (st[SLAM_STAT_ALLNAN] == 2) return slam_fail(ctx, SLAM_E_LIMITS, "Invalid vmin or vmax");
     if (st[SLAM_STAT_ALLNAN]) return slam_fail(ctx, SLAM_E_ALLNAN, "matrix has no finite cell");
     if (vmin_vmax_out) {
         uint64_t lo = (uint64_t)st[SLAM_STAT_VMIN_LO] | ((uint64_t)st[SLAM_STAT_VMIN_HI] << 32);

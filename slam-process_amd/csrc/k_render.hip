@@ -192,30 +192,56 @@ __device__ void axis_map(const double *e, int n, int npix, bool flip, int16_t *m
 }
 
 // scale + colour of a compact h x w matrix `m` (row stride w) -> cells RGBA; returns limits used.
-__device__ void colour_block(const double *m, int h, int w, int use_log, double vmin, double vmax,
-                             double mn, double mx, const uint8_t *lut, uint8_t *cells, double *lo_out,
-                             double *hi_out)
+// Limits of the colour scale as the reference's figure ends up with them (excel_heatmap_v3.py:409-423, :449-457).
+// Linear scale: pcolormesh gets no norm and no limits, so vmin / vmax given by the caller play no part and the scale
+// spans the finite data.  Log scale: LogNorm over the data shifted by (1e-6 - min), given limits shifted alike;
+// a limit that is not positive after the shift makes the norm fail ("Invalid vmin or vmax").  The colour bar then
+// passes the limits through matplotlib's nonsingular(expander=0.1): an empty interval grows by a tenth of each end
+// (or to +-0.1 around zero), and limits given in reverse come out as (0.9 * smaller, larger) -- the smaller end is
+// expanded while both ends momentarily hold it.  Returns false for the invalid case.
+__device__ bool scale_limits(int use_log, double vmin, double vmax, double mn, double mx, double *lo_out, double *hi_out)
 {
-    double lo, hi, tlo = 0.0, span;
+    double lo, hi;
     if (use_log) {
         lo = isnan(vmin) ? (mn - mn + 1e-6) : (vmin - mn + 1e-6);
         hi = isnan(vmax) ? (mx - mn + 1e-6) : (vmax - mn + 1e-6);
-        tlo = log10(lo);
-        span = log10(hi) - tlo;
+        if (!(lo > 0.0) || !(hi > 0.0) || isinf(lo) || isinf(hi)) return false;
     } else {
-        lo = isnan(vmin) ? mn : vmin;
-        hi = isnan(vmax) ? mx : vmax;
-        span = hi - lo;
+        lo = mn;
+        hi = mx;
+    }
+    if (hi < lo) {
+        const double t = lo;
+        lo = hi - 0.1 * fabs(hi);
+        hi = t;
+    } else {
+        const double big = fmax(fabs(lo), fabs(hi));
+        if (big < 2.2250738585072014e-287) { lo = -0.1; hi = 0.1; }
+        else if (hi - lo <= big * 1e-15) { lo -= 0.1 * fabs(lo); hi += 0.1 * fabs(hi); }
     }
     *lo_out = lo;
     *hi_out = hi;
+    return true;
+}
+
+// Cell colours for limits from scale_limits: index = floor(norm * 256) clipped to the table, holes transparent.
+__device__ void colour_block(const double *m, int h, int w, int use_log, double mn, double lo, double hi,
+                             const uint8_t *lut, uint8_t *cells)
+{
+    double tlo = 0.0, span;
+    if (use_log) {
+        tlo = log10(lo);
+        span = log10(hi) - tlo;
+    } else {
+        span = hi - lo;
+    }
     for (int c = threadIdx.x; c < h * w; c += blockDim.x) {
         const double v = m[c];
         uchar4 px = make_uchar4(255, 255, 255, 0);           // set_bad((1,1,1,0)) (:447)
         if (finite_d(v)) {
             double nrm;
-            if (use_log) nrm = span != 0.0 ? (log10(v - mn + 1e-6) - tlo) / span : 0.0;
-            else nrm = span != 0.0 ? (v - lo) / span : 0.0;
+            if (use_log) nrm = (log10(v - mn + 1e-6) - tlo) / span;
+            else nrm = (v - lo) / span;
             double x = floor(nrm * 256.0);
             int idx = isnan(x) ? 0 : (x < 0.0 ? 0 : (x > 255.0 ? 255 : (int)x));
             px = make_uchar4(lut[idx * 3], lut[idx * 3 + 1], lut[idx * 3 + 2], 255);
@@ -293,7 +319,11 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
         return;
     }
     double lo, hi;
-    colour_block(fin, h, w, rp.use_log, rp.vmin, rp.vmax, mn, mx, rp.lut, cells, &lo, &hi);
+    if (!scale_limits(rp.use_log, rp.vmin, rp.vmax, mn, mx, &lo, &hi)) {
+        if (tid == 0) st[SLAM_STAT_ALLNAN] = 2;
+        return;
+    }
+    colour_block(fin, h, w, rp.use_log, mn, lo, hi, rp.lut, cells);
     if (tid == 0) { put_f64_stat(st, SLAM_STAT_VMIN_LO, lo); put_f64_stat(st, SLAM_STAT_VMAX_LO, hi); }
     if (tid == 0) edges_of(ang_c, w, edge);
     __syncthreads();
@@ -376,7 +406,11 @@ __global__ __launch_bounds__(256) void k_render_only(const double *mat, int h, i
         return;
     }
     double lo, hi;
-    colour_block(mat, h, w, use_log, vmin, vmax, mn, mx, lut, cells, &lo, &hi);
+    if (!scale_limits(use_log, vmin, vmax, mn, mx, &lo, &hi)) {
+        if (tid == 0) stats[SLAM_STAT_ALLNAN] = 2;
+        return;
+    }
+    colour_block(mat, h, w, use_log, mn, lo, hi, lut, cells);
     if (tid == 0) { put_f64_stat(stats, SLAM_STAT_VMIN_LO, lo); put_f64_stat(stats, SLAM_STAT_VMAX_LO, hi); }
     if (tid == 0) edges_of(aoa, w, edge);
     __syncthreads();

@@ -263,6 +263,8 @@ def generate_heatmap(matrix: np.ndarray, aod_list: List[float], aoa_list: List[f
     except ops._lib.SlamError as e:
         if e.code == ops._lib.E_ALLNAN:
             raise ValueError("矩阵数据全为NaN，无法生成热力图")
+        if e.code == ops._lib.E_LIMITS:
+            raise ValueError("Invalid vmin or vmax")           # what the reference's LogNorm says (:415-418)
         raise
     fig, ax = plt.subplots(figsize=(10, 8), dpi=120)
     ax.pcolormesh(_edges(aoa_list), _edges(aod_list), cells.astype(np.float64) / 255.0, shading="flat")

@@ -282,7 +282,8 @@ def test_pivot_matches_oracle(ops, mapping):
 def test_render_edge_cases(ops, lut):
     one = np.array([[5.0]])
     cells, tile, lo, hi = ops.render(one, [1.0], [2.0], lut, W=8, H=4)
-    assert (lo, hi) == (5.0, 5.0) and cells[0, 0].tolist() == [*lut[0], 255] and (tile == cells[0, 0]).all()
+    # one value: the colour bar widens the empty interval by a tenth, so the value sits in the middle of the scale
+    assert (lo, hi) == (4.5, 5.5) and cells[0, 0].tolist() == [*lut[128], 255] and (tile == cells[0, 0]).all()
     nanm = np.full((3, 3), np.nan)
     from slamhip._lib import SlamError, E_ALLNAN
     with pytest.raises(SlamError) as ei:
@@ -295,6 +296,32 @@ def test_render_edge_cases(ops, lut):
 
 
 # ---- synthetic generator + batched pipeline ----------------------------------------------------------------------
+def test_colour_limits_follow_the_reference_figure(ops, lut):
+    """slam_render on the reference's limit cases: the linear scale ignores given limits, empty and reversed
+    intervals come out as matplotlib's colour bar leaves them, a log limit at or below the data minimum fails with
+    matplotlib's message; golden limits and cell colours from the reference's own figure."""
+    import excel_heatmap_v3 as E
+    doc = json.load(open(os.path.join(GOLDEN, "limit_cases.json")))
+    for k, e in doc.items():
+        mat = np.array([[np.nan if v is None else v for v in r] for r in e["matrix"]])
+        if "error" in e:
+            with pytest.raises(ops._lib.SlamError) as ei:
+                ops.render(mat, e["aod"], e["aoa"], lut, use_log=e["use_log"], vmin=e["vmin_in"], vmax=e["vmax_in"], W=8, H=8)
+            assert ei.value.code == ops._lib.E_LIMITS
+            with pytest.raises(ValueError, match=e["message"]):
+                E.generate_heatmap(mat, e["aod"], e["aoa"], "/tmp/_limits.png", "t", use_log=e["use_log"], vmin=e["vmin_in"],
+                                   vmax=e["vmax_in"], blur_sigma=0.0)
+            continue
+        cells, tile, lo, hi = ops.render(mat, e["aod"], e["aoa"], lut, use_log=e["use_log"], vmin=e["vmin_in"],
+                                         vmax=e["vmax_in"], W=8, H=8)
+        assert (lo, hi) == (e["vmin"], e["vmax"]), k
+        d = np.abs(cells.astype(int) - np.array(e["cells"]))
+        if e["use_log"]:      # log10 may differ in the last ulp between libraries: one LUT step at a bin edge
+            assert d.max() <= 3 and (d.max(axis=2) > 0).sum() <= 1, k
+        else:
+            assert d.max() == 0, k
+
+
 def test_synth_device_matches_numpy():
     import torch
     from slamhip import synth
@@ -358,6 +385,51 @@ def test_batched_pipeline_against_oracle(mapping, lut, shape, two_pass, monkeypa
     from slamhip.pipeline import expand_compact
     again = expand_compact(pipe.compact[pipe.compact_slot].clone(), F, 256, 128)
     assert torch.equal(again, pipe.tiles[:F])
+
+
+@pytest.mark.parametrize("opts", [dict(use_log=True), dict(use_log=True, blur_sigma=0.0), dict(blur_sigma=0.0),
+                                  dict(blur_sigma=2.0), dict(vmin=20000.0, vmax=60000.0), dict(vmin=45000.0),
+                                  dict(use_log=True, vmin=10.0, vmax=30000.0), dict(tile=(250, 77)), dict(tile=(3, 5))])
+def test_batched_render_options(mapping, lut, opts):
+    """The batched call's render settings -- log scale, fixed limits, no blur / wider blur, tile sizes that are not
+    multiples of four -- against the oracle's generate_heatmap restatement on the same corrected rows."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 8, 512, 2
+    o = dict(opts)
+    W, H = o.pop("tile", (96, 64))
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=300)
+    pipe = FramePipeline(F, tl, tile_w=W, tile_h=H, mapping=mapping, lut=lut, **o)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    st = pipe.stats_host()
+    sigma = o.get("blur_sigma", 1.0)
+    for f in range(F):
+        kept = pipe.frame_kept(f, st)
+        mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mapping)
+        if o.get("use_log") and o.get("vmin") == 10.0:       # below the data: the reference's LogNorm fails
+            with pytest.raises(ValueError, match="Invalid vmin or vmax"):
+                O.render(O.blur_nan_aware(mat, sigma), aod, aoa, lut, use_log=True, vmin=10.0, vmax=30000.0, blur_sigma=0.0, W=W, H=H)
+            assert int(st[f, 9]) == 2 and not pipe.frame_tile(f)[..., 3].any()
+            continue
+        full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
+        ob = O.blur_nan_aware(mat, sigma)
+        assert np.array_equal(np.isnan(bl), np.isnan(ob))
+        fin = np.isfinite(ob)
+        assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL
+        r = O.render(bl, aod, aoa, lut, use_log=o.get("use_log", False), vmin=o.get("vmin"), vmax=o.get("vmax"),
+                     blur_sigma=0.0, W=W, H=H)
+        assert (lo, hi) == (r["vmin"], r["vmax"])
+        tile = pipe.frame_tile(f)
+        assert tile.shape == (H, W, 4)
+        if o.get("use_log"):          # log10 may differ in the last ulp between libraries: one LUT step at bin edges
+            d = np.abs(tile.astype(int) - r["tile"].astype(int))
+            assert (d.max(axis=2) > 0).mean() <= 0.01 and d.max() <= 3
+        else:
+            assert np.array_equal(tile, r["tile"])
 
 
 def _hostile_streams():

@@ -176,3 +176,20 @@ def test_oracle_skipped_tokens_match_the_reference_log():
         lines = ["跳过非16进制单字节token[%d]='%s'" % it for it in O.skipped_tokens_py(raw)]
         assert lines == e["lines"], name
         assert len(O.read_bytes(raw)) == e["n_bytes"], name
+
+
+def test_oracle_colour_limits_match_the_reference_figure():
+    """Given, equal, reversed and invalid vmin / vmax on both scales: limits of the mesh's norm, cell colours and
+    failures as the reference's generate_heatmap produced them (tests/golden/make_limit_cases.py)."""
+    lut = np.load(os.path.join(GOLDEN, "viridis_lut.npy"))
+    doc = json.load(open(os.path.join(GOLDEN, "limit_cases.json")))
+    assert len(doc) == 72
+    for k, e in doc.items():
+        mat = np.array([[np.nan if v is None else v for v in r] for r in e["matrix"]])
+        if "error" in e:
+            with pytest.raises(ValueError, match=e["message"]):
+                O.render(mat, e["aod"], e["aoa"], lut, use_log=e["use_log"], vmin=e["vmin_in"], vmax=e["vmax_in"], blur_sigma=0.0, W=8, H=8)
+            continue
+        r = O.render(mat, e["aod"], e["aoa"], lut, use_log=e["use_log"], vmin=e["vmin_in"], vmax=e["vmax_in"], blur_sigma=0.0, W=8, H=8)
+        assert (r["vmin"], r["vmax"]) == (e["vmin"], e["vmax"]), k
+        assert np.array_equal(r["cells"].astype(int), np.array(e["cells"])), k
