@@ -18,6 +18,8 @@ import sys
 from pathlib import Path
 from typing import List, Tuple
 
+import numpy as np
+
 from slamhip import ops, xlsx
 
 HEADER = ["FLAG", "UE_Beam[5:0]十进制", "BS_Beam[5:0]十进制", "RSS十进制", "CLK十进制"]   # :110-116
@@ -59,6 +61,12 @@ def skipped_token_lines(raw: bytes) -> List[str]:
 
 def _parse_groups(bytes_list: List[int], logger: logging.Logger) -> Tuple[List[Tuple[int, int, int, int, int]], int, int]:
     """Byte values -> (rows of (flag, ue, bs, rss, clk), valid, discarded) (:41-103)."""
+    if len(bytes_list) and not isinstance(bytes_list, (bytes, bytearray)):
+        arr = np.asarray(bytes_list)
+        if arr.dtype.kind not in "iu" or arr.min() < 0 or arr.max() > 255:
+            # _read_bytes only yields 0..255; anything else cannot be carried as device bytes without changing
+            # which positions look like flag bytes
+            raise ValueError("bytes_list must hold integers in 0..255")
     cols, valid, discarded = ops.parse_records(bytes_list)
     rows = list(zip(cols["flag"].tolist(), cols["ue"].tolist(), cols["bs"].tolist(),
                     cols["rss"].tolist(), cols["clk"].tolist()))

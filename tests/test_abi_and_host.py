@@ -244,3 +244,15 @@ def test_heatmap_reader_cleaning_rules(tmp_path):
     xlsx.write_table(m, ["BeamID", "Angle"], [[0, 1, 64, -1, None, 2], [-10.0, None, 5.0, 6.0, 7.0, "30"]])
     mp = E.read_mapping(m)
     assert set(mp) == {0, 1, 2} and mp[0] == -10.0 and np.isnan(mp[1]) and mp[2] == 30.0
+
+
+def test_parser_refuses_values_that_are_not_bytes():
+    """_parse_groups takes what _read_bytes yields (0..255); other integers are refused before any device call."""
+    import importlib.util
+    import logging
+    spec = importlib.util.spec_from_file_location("mine_serial_hex_to_excel_v3_rng", os.path.join(PKG, "serial_hex_to_excel_v3.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    for bad in ([0x33, 307], [-205, 1], [0.5, 1]):
+        with pytest.raises(ValueError, match="0..255"):
+            S._parse_groups(bad, logging.getLogger("t"))
