@@ -212,6 +212,22 @@ extern "C" int slam_timing_read(slam_ctx *ctx, char *names_out, uint32_t *launch
 
 static uint32_t round16(uint64_t v) { return (uint32_t)((v + 15) & ~uint64_t(15)); }
 
+namespace {
+__global__ __launch_bounds__(256) void k_zero_words(uint32_t *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+int slam_zero_async(slam_ctx *ctx, void *dev, size_t bytes)
+{
+    const size_t n = bytes / 4;
+    if (n == 0) return SLAM_OK;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 4096);
+    SLAM_LAUNCH(ctx, "zero", k_zero_words, dim3(blocks), dim3(256), (uint32_t *)dev, n);
+    return SLAM_OK;
+}
+
 static int h2d(slam_ctx *ctx, void *dst, const void *src, size_t n)
 {
     if (n) SLAM_HIP(ctx, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx->stream));
@@ -749,7 +765,7 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     const uint32_t kept_stride = (bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : cws.rt_nkept;
     if (stages & 1u) {
-        SLAM_HIP(ctx, hipMemsetAsync(bt->stats_dev, 0, (size_t)F * SLAM_STAT_WORDS * 4, ctx->stream));
+        SLAM_TRY(slam_zero_async(ctx, bt->stats_dev, (size_t)F * SLAM_STAT_WORDS * 4));
         frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev, nullptr, 0, nullptr};
         SLAM_TRY(frame_decode(ctx, bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, fs, F, bt->max_text_len, fws, bp.nt_max,
                               rows, bt->stats_dev));

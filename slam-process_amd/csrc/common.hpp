@@ -88,6 +88,10 @@ void slam_timer_end(slam_ctx *ctx, int token);
                              hipGetErrorString(le__));                                         \
     } while (0)
 
+// Zero `bytes` (a multiple of 4) at a 4-byte aligned device address with a kernel of the library's own on the ctx's
+// stream: an ordinary kernel node when the caller captures the stream into a graph.
+int slam_zero_async(slam_ctx *ctx, void *dev, size_t bytes);
+
 static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------------

@@ -448,8 +448,8 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
 {
     if (F == 0) return SLAM_OK;
     if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
-    SLAM_HIP(ctx, hipMemsetAsync(ws.sum, 0, (size_t)F * MAX_CELLS * 8, ctx->stream));
-    SLAM_HIP(ctx, hipMemsetAsync(ws.cnt, 0, (size_t)F * MAX_CELLS * 4, ctx->stream));
+    SLAM_TRY(slam_zero_async(ctx, ws.sum, (size_t)F * MAX_CELLS * 8));
+    SLAM_TRY(slam_zero_async(ctx, ws.cnt, (size_t)F * MAX_CELLS * 4));
     constexpr uint32_t chunk = 1u << pivot_chunk<T32>::log2;
     dim3 grid((row_cap + chunk - 1) / chunk, F), block(1024);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,

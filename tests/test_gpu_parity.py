@@ -432,6 +432,51 @@ def test_batched_render_options(mapping, lut, opts):
             assert np.array_equal(tile, r["tile"])
 
 
+def test_batched_call_captured_into_a_graph(mapping, lut):
+    """The batched call enqueues kernels only (its workspace is reserved beforehand, nothing synchronises), so a caller
+    may capture it into a graph: replays on new text in the same buffer give what direct calls give."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 16, 1024, 4
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    texts = [synth_frames(F, B, N, first_frame=k) for k in (0, 50, 90)]
+    pipe = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    want = []
+    for t in texts:
+        pipe.run(t)
+        torch.cuda.synchronize()
+        want.append((pipe.tiles.clone(), pipe.stats.clone(), pipe.k_rss.clone(), pipe.kept_cnt.clone()))
+    buf = texts[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.run(buf)                                        # warm-up on the capturing stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        pipe.run(buf)
+    for k in (1, 2, 0, 2):
+        buf.copy_(texts[k])
+        pipe.tiles.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        tiles, stats, rss, cnt = want[k]
+        assert torch.equal(pipe.tiles, tiles) and torch.equal(pipe.stats, stats), k
+        assert torch.equal(pipe.kept_cnt, cnt), k
+        st = pipe.stats_host()
+        for f in range(F):                                   # kept rows: the used entries of every block
+            a = pipe.frame_kept(f, st)["rss"]
+            pipe_rss = pipe.k_rss
+            pipe.k_rss = rss
+            b = pipe.frame_kept(f, st)["rss"]
+            pipe.k_rss = pipe_rss
+            assert np.array_equal(a, b), (k, f)
+
+
 def _hostile_streams():
     """Byte streams that stress the resynchronising scan: flag bytes everywhere, records cut by the end of the
     data at every offset around a tile edge, long stretches without any record."""
