@@ -206,8 +206,12 @@ else:
 dist.destroy_process_group()
 ''')
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:                              # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "ok").exists()

@@ -396,8 +396,12 @@ def test_batch_driver_two_ranks_gather_to_rank_zero(tmp_path):
         (tmp_path / f"cap{k}.txt").write_bytes(texts[-1])
     out = tmp_path / "tiles"
     env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    import socket
+    with socket.socket() as sk:                              # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", "-m", "slamhip.run_logs", str(tmp_path), "--out-dir", str(out), "--tile", "256",
+           "--master-port", str(port), "-m", "slamhip.run_logs", str(tmp_path), "--out-dir", str(out), "--tile", "256",
            "--backend", "gloo"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
