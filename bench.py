@@ -78,7 +78,14 @@ def cpu_baseline(B, N, n_frames, tile):
     total = sum(r["n"] for r in res)
     slowest = max(r["dt"] for r in res)
     single = sum(r["n"] / r["dt"] for r in res) / len(res)
+    ref_offline = None                  # the reference's own Python, timed once in the build container (it cannot travel)
+    ref_json = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
+    if os.path.exists(ref_json) and (B, N) == (256, 4096):
+        rj = json.load(open(ref_json))
+        ref_offline = dict(frames_per_second_one_thread=round(rj["implied_frames_per_second_one_thread"], 5),
+                           seconds_per_frame=round(rj["implied_seconds_per_256x4096_frame"], 1), where=rj["what"])
     return dict(value=total / slowest, unit="frames/s", cores=cores, kind="port", single_core_value=round(single, 3),
+                reference_offline=ref_offline,
                 sample=f"{total} synthetic {B}x{N} frames through oracle/ (sequential C scan + brute-force baseline "
                        f"search + NumPy blur/raster), {per} per worker process, {cores} single-threaded workers on "
                        f"{cores} of {os.cpu_count()} visible host cores, slowest worker {slowest:.1f} s "
