@@ -459,3 +459,58 @@ def test_batch_beyond_4_gib_arrays_matches_small_batches():
     kept = big.frame_kept(f, st)
     for k in kept_o:
         assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+
+
+def test_three_command_lines_end_to_end(tmp_path):
+    """The reference's three command lines, run as scripts (serial_hex_to_excel_v3.py IN OUT; bs_beam_correction.py
+    --input / --run-tests; excel_heatmap_v3.py --input --mapping --output): workbooks, log file, summary line and PNG
+    as the reference's scripts leave them, with the rows the reference gave for this capture."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import PKG
+    from slamhip import xlsx
+    z = np.load(os.path.join(GOLDEN, "log1.npz"))
+    cap = tmp_path / "cap.txt"
+    cap.write_bytes(z["text"].tobytes())
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""), MPLBACKEND="Agg")
+
+    def run(*args):
+        return subprocess.run([sys.executable, *map(str, args)], env=env, capture_output=True, text=True, timeout=300, cwd=tmp_path)
+
+    out = tmp_path / "cap.xlsx"
+    r = run(os.path.join(PKG, "serial_hex_to_excel_v3.py"), cap, out)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert f"有效组数={int(z['valid'])} 丢弃组数={int(z['discarded'])} 输出={out} 日志={out.with_suffix('.log')}" in r.stdout
+    t = xlsx.read_table(str(out), "Parsed")
+    got = np.array([t[h] for h in t], np.int64).T
+    assert np.array_equal(got, z["rows"])
+    log = out.with_suffix(".log").read_text(encoding="utf-8")
+    assert log.count("丢弃组，") == int(z["discarded"]) and "跳过非16进制单字节token[0]='«'" in log
+    r = run(os.path.join(PKG, "serial_hex_to_excel_v3.py"), tmp_path / "missing.txt", out)
+    assert r.returncode == 0 and "输入文件不存在" in r.stdout
+
+    r = run(os.path.join(PKG, "bs_beam_correction.py"), "--input", out)
+    assert r.returncode == 0, r.stderr[-1500:]
+    filt = tmp_path / "cap_filtered.xlsx"
+    t = xlsx.read_table(str(filt))
+    assert list(t) == ["UE_Beam", "BS_Beam", "RSS值", "CLK值"]
+    assert np.array_equal(np.array([t[h] for h in t], np.int64).T, z["kept"])
+    assert f"已生成过滤后的修正文件: {filt} 行数={len(z['kept'])}" in r.stderr
+    r = run(os.path.join(PKG, "bs_beam_correction.py"), "--run-tests")
+    assert r.returncode == 0 and "OK" in r.stderr
+    r = run(os.path.join(PKG, "bs_beam_correction.py"), "--input", tmp_path / "missing.xlsx")
+    assert r.returncode == 1 and "处理失败" in r.stderr
+
+    mp = json.load(open(os.path.join(GOLDEN, "beam_angle.json")))
+    mpx = tmp_path / "beam_angle.xlsx"
+    xlsx.write_table(str(mpx), ["BeamID", "Angle"], [[int(k) for k in mp], [float(v) for v in mp.values()]])
+    png = tmp_path / "pics" / "h.png"
+    png.parent.mkdir()            # the log file goes next to the PNG before anything creates that directory (:613-619)
+    r = run(os.path.join(PKG, "excel_heatmap_v3.py"), "--input", filt, "--mapping", mpx, "--output", png)
+    assert r.returncode == 0, r.stderr[-1500:] + r.stdout[-1500:]
+    assert Image.open(png).size == (1500, 1200)
+    assert "logscale=False" in r.stdout and "blur_sigma=1.0" in r.stdout and f"输出PNG: {png}" in r.stdout
+    assert list((tmp_path / "pics").glob("excel_heatmap_*.log"))
+    r = run(os.path.join(PKG, "excel_heatmap_v3.py"), "--input", filt, "--mapping", tmp_path / "nomap.xlsx", "--output", png)
+    assert r.returncode == 1 and "执行失败" in r.stdout
