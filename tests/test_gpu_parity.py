@@ -608,6 +608,46 @@ def _wrap_stream(cycle: int, seed: int, groups: int = 6, rows_per_group: int = 7
     return bytes(out)
 
 
+def test_batched_correction_mixed_frames_in_one_batch(mapping, lut):
+    """One batch whose frames take different routes through the correction: tables that fit a wave, groups of 100, 300
+    and 1500 baselines (the frame is left to the full kernel), groups of three rows (a workgroup spans more groups
+    than it stages and defers on its own), an empty frame -- neighbours in the batch do not disturb each other."""
+    import torch
+    from slamhip.pipeline import FramePipeline
+    cycle = 61000
+    tiny = _wrap_stream(cycle, 21, groups=900, rows_per_group=3, n_baselines=1)
+    streams = [_wrap_stream(cycle, 5), _wrap_stream(cycle, 6, groups=2, rows_per_group=400, n_baselines=100), b"",
+               _wrap_stream(cycle, 7, groups=2, rows_per_group=1000, n_baselines=300), tiny, _wrap_stream(cycle, 8),
+               _wrap_stream(cycle, 9, groups=1, rows_per_group=4000, n_baselines=1500), _wrap_stream(cycle, 10)]
+    offs, lens, blob = [], [], bytearray()
+    for sbytes in streams:
+        while len(blob) % 16:
+            blob.append(0xEE)
+        offs.append(len(blob)); lens.append(len(sbytes)); blob += sbytes
+    blob += b"\xEE" * 64
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
+    pipe.set_layout(offs, lens)
+    pipe.run(text)
+    st = pipe.stats_host()
+    big = 0
+    for f, sbytes in enumerate(streams):
+        rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+        assert (int(st[f, 2]), int(st[f, 3]), int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (v, d, ng, nb, len(kept_o["ue"])), f
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
+        big += nb > 64 * max(ng, 1)
+        if len(kept_o["ue"]):
+            mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
+            full = pipe.frame_matrix(f, st)[0]
+            assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True), f
+        else:
+            assert int(st[f, 9]) == 1
+    assert big >= 3
+
+
 @pytest.mark.parametrize("cycle,tol", [(61000, 500), (1000, 499), (1000, 500), (1000, 700), (977, 0), (64, 31)])
 def test_batched_correction_wraps_and_tolerances(mapping, lut, cycle, tol):
     """Baseline phases at the ends of the cycle, rows across the wrap, ties, tolerances below / at / above half a
