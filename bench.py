@@ -99,6 +99,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: run the N ranks as a child job (nothing here has touched the GPU yet)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.run(cmd).returncode)
     cpu_line = None
     if rank == 0 and world == 1 and a.cpu_frames > 0:      # before anything here initialises the GPU
         cpu_line = cpu_baseline(a.beams, a.samples, a.cpu_frames, a.tile)
