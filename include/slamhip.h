@@ -190,6 +190,10 @@ typedef struct slam_batch {
     int16_t *rowmap_dev;          /* [F*tile_h] pixel row -> cell row                             */
 } slam_batch;
 
+/* sizeof(slam_batch) as the library was built with: a binding compares it with its own mirror of the struct
+ * before the first call (no counterpart in the reference, which has no binary interface). */
+size_t slam_batch_sizeof(void);
+
 #define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
 #define SLAM_TILE_SLOTS     276   /* entries reserved per tile in the decoded-record arrays        */
 #define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays                 */

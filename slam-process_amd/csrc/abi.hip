@@ -714,6 +714,8 @@ extern "C" int slam_raster_dev(slam_ctx *ctx, const uint8_t *cells_dev, const in
     return raster_only(ctx, cells_dev, colmap_dev, rowmap_dev, stats_dev, n_frames, tile_w, tile_h, tile_dev);
 }
 
+extern "C" size_t slam_batch_sizeof(void) { return sizeof(slam_batch); }
+
 extern "C" int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch)
 {
     REQUIRE_CTX(ctx);

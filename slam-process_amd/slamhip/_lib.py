@@ -25,7 +25,7 @@ TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
-    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_raster_dev", "slam_reserve_workspace",
+    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
@@ -102,6 +102,10 @@ def load() -> C.CDLL:
                                     C.c_int, C.c_int, vp]
         lib.slam_process_frames_dev.argtypes = [vp, C.POINTER(Batch), u32]
         lib.slam_reserve_workspace.argtypes = [vp, C.POINTER(Batch)]
+        lib.slam_batch_sizeof.restype = sz
+        if lib.slam_batch_sizeof() != C.sizeof(Batch):
+            raise RuntimeError(f"{LIB_PATH}: slam_batch is {lib.slam_batch_sizeof()} bytes in the library, "
+                               f"{C.sizeof(Batch)} in this binding -- rebuild the library or update the binding")
         lib.slam_raster_dev.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, vp]
         lib.slam_synth_text_len.argtypes = [u32, u32]
         lib.slam_synth_text_len.restype = sz
