@@ -514,3 +514,25 @@ def test_three_command_lines_end_to_end(tmp_path):
     assert list((tmp_path / "pics").glob("excel_heatmap_*.log"))
     r = run(os.path.join(PKG, "excel_heatmap_v3.py"), "--input", filt, "--mapping", tmp_path / "nomap.xlsx", "--output", png)
     assert r.returncode == 1 and "执行失败" in r.stdout
+
+
+def test_plain_c_host_of_the_abi(tmp_path):
+    """examples/cabi_demo.c, a C program with no Python in it, through slam_parse_text and slam_correct on a committed
+    capture head: the reference's counters and the corrected rows' fingerprints."""
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "examples", "cabi_demo")
+    assert os.path.exists(demo), "build it with __graft_entry__.build()"
+    z = np.load(os.path.join(GOLDEN, "log2.npz"))
+    cap = tmp_path / "cap.txt"
+    cap.write_bytes(z["text"].tobytes())
+    r = subprocess.run([demo, str(cap)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    kept = z["kept"]
+    assert (d["valid"], d["discarded"], d["kept"]) == (int(z["valid"]), int(z["discarded"]), len(kept))
+    assert d["groups"] == int(z["gid"].max()) + 1 and d["baselines"] == len(z["baselines"])
+    assert d["bs_fingerprint"] == int((kept[:, 1] * (np.arange(len(kept)) % 251 + 1)).sum())
+    assert d["clk_sum"] == int(kept[:, 3].sum())
+    r = subprocess.run([demo, str(tmp_path / "none.txt")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
