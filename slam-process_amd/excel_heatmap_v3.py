@@ -215,7 +215,9 @@ def compute_rssi_matrix(df: pd.DataFrame, logger: Optional[logging.Logger] = Non
 
 
 def gaussian_kernel(sigma: float) -> np.ndarray:
-    """Odd-sized normalised Gaussian of about 6 sigma (reference :320-333); [[1.0]] when sigma <= 0."""
+    """Odd-sized normalised Gaussian of about 6 sigma (reference :320-333); [[1.0]] when sigma <= 0.  A few dozen
+    numbers worked out on the host, as the library works out its own copy before a blur; the blur itself
+    (gaussian_blur_nan_aware) runs on the device."""
     if sigma <= 0:
         return np.ones((1, 1), dtype=np.float64)
     size = max(3, int(math.ceil(6 * sigma)))
