@@ -71,3 +71,39 @@ def test_reference_functions_on_full_captures(ref):
         arr = np.array(rows_ref, dtype=np.int64)
         for j, k in enumerate(("flag", "ue", "bs", "rss", "clk")):
             assert np.array_equal(rows[k].astype(np.int64), arr[:, j])
+
+
+def test_reference_functions_on_a_synthetic_frame(ref, tmp_path):
+    """The benchmark's kind of data (slamhip/synth.py, 8 sweeps of 1024 records) through the reference's own
+    _read_bytes, _parse_groups and the group loop of process_excel_filtered, against the oracle: the frames the
+    throughput is measured on are covered by the same pin as the captures."""
+    import importlib.util
+    import pandas as pd
+    from pathlib import Path
+    from slamhip import synth
+    spec = importlib.util.spec_from_file_location("ref_bs_beam_correction_syn", os.path.join(REFERENCE, "bs_beam_correction.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    lg = logging.getLogger("pin")
+    text = synth.make_frame_text(8, 1024, 3).tobytes()
+    p = tmp_path / "f.txt"
+    p.write_bytes(text)
+    by_ref = ref._read_bytes(Path(p), lg)
+    rows_ref, v_ref, d_ref = ref._parse_groups(by_ref, lg)
+    by = O.read_bytes(text)
+    rows, v, d = O.parse_groups(by)
+    assert by.tolist() == by_ref and (v, d) == (v_ref, d_ref)
+    arr = np.array(rows_ref, dtype=np.int64)
+    for j, k in enumerate(("flag", "ue", "bs", "rss", "clk")):
+        assert np.array_equal(rows[k].astype(np.int64), arr[:, j])
+    df = B._coerce_types(pd.DataFrame(rows_ref, columns=[B.FLAG_COL, B.UE_BEAM_COL, B.BS_BEAM_COL, B.RSS_COL, B.CLK_COL]))
+    df["_gid"] = B._detect_groups(df)
+    pieces = []
+    for g, sub in df.groupby("_gid", sort=True):
+        f = B._filter_group_corrected(sub, B._identify_baselines(sub))
+        if not f.empty:
+            pieces.append(f)
+    res = pd.concat(pieces, ignore_index=True).to_numpy().astype(np.int64)
+    kept, ng, nb = O.filter_corrected(*arr.T)
+    assert ng == int(df["_gid"].max()) + 1 == 8
+    assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), res)
