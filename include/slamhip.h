@@ -149,7 +149,7 @@ typedef struct slam_batch {
     const uint8_t *text_dev;      /* all frames' text; readable up to 32 bytes past the last frame */
     const uint64_t *text_off_dev; /* [F] byte offset of each frame's text                        */
     const uint32_t *text_len_dev; /* [F] text bytes of each frame                                */
-    uint32_t n_frames;            /* F                                                            */
+    uint32_t n_frames;            /* F, at most 65535 per call                                    */
     uint32_t max_text_len;        /* max over frames of text_len (host-known upper bound)        */
     uint32_t src_is_bytes;        /* 0: text_dev holds hex text in the capture format;            */
                                   /* 1: it holds already-unpacked data bytes (slam_hex_unpack)    */

@@ -684,6 +684,10 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
 {
     if (!bt || !bt->text_dev || !bt->text_off_dev || !bt->text_len_dev || !bt->stats_dev)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: text, offsets, lengths and stats are required");
+    if (bt->n_frames > 65535u)          // frames are the y (z for the raster) dimension of the launch grids
+        return slam_fail(ctx, SLAM_E_RANGE, "slam_batch: at most 65535 frames per call, got %u", bt->n_frames);
+    if (bt->tile_dev && (int64_t)bt->tile_h > 16 * 65535ll)
+        return slam_fail(ctx, SLAM_E_RANGE, "slam_batch: tile of %d x %d is beyond the raster kernel's grid", bt->tile_w, bt->tile_h);
     bp.st_max = slot_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
     if (bt->row_cap % 16 || (uint64_t)bt->row_cap < (uint64_t)bp.st_max * SLOT_ROWS)
         return slam_fail(ctx, SLAM_E_INVALID,

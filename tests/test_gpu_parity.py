@@ -761,7 +761,7 @@ def test_batched_api_rejects_bad_arguments(mapping, lut):
     pipe = FramePipeline(F, tl, tile_w=64, tile_h=64, mapping=mapping, lut=lut)
     pipe.set_uniform_layout(F, stride, tl)
     pipe.run(text)                                           # the untouched batch works
-    good = {k: getattr(pipe.bt, k) for k in ("row_cap", "flag_dev", "lut_dev", "cycle")}
+    good = {k: getattr(pipe.bt, k) for k in ("row_cap", "flag_dev", "lut_dev", "cycle", "n_frames", "tile_h")}
 
     def expect_error(field, value, code):
         setattr(pipe.bt, field, value)
@@ -778,6 +778,8 @@ def test_batched_api_rejects_bad_arguments(mapping, lut):
     expect_error("lut_dev", None, _lib.E_INVALID)
     expect_error("cycle", 0, _lib.E_INVALID)
     expect_error("cycle", (1 << 30) + 1, _lib.E_INVALID)
+    expect_error("n_frames", 65536, _lib.E_RANGE)                          # frames ride on a grid dimension
+    expect_error("tile_h", 16 * 65535 + 1, _lib.E_RANGE)
     pipe.run(text)                                           # and still works afterwards
     st = pipe.stats_host()
     assert int(st[0, 2]) > 0 and int(st[0, 6]) > 0
