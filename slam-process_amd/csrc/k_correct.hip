@@ -17,6 +17,8 @@
 // leaves, with the per-tile bits, counts and baseline payloads it already derived: k_tile_bits (only for what
 // the framing pass could not do) -> k_tile_scan -> k_tile_groups -> k_bl_sort[_small] -> k_rows_finish, which
 // writes the kept rows into per-block slots, so neither a corrected-BS column nor a second scan is needed.
+// k_rows_finish is launched twice in that path: its lean build (register-resident tables only) on frames whose
+// groups all have at most 64 baselines, then its full build on what the lean one left; the sort marks the frames.
 
 #include <type_traits>
 
