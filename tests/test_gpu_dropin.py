@@ -539,3 +539,36 @@ def test_plain_c_host_of_the_abi(tmp_path):
     assert d["clk_sum"] == int(kept[:, 3].sum())
     r = subprocess.run([demo, str(tmp_path / "none.txt")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+def test_complete_capture_end_to_end():
+    """A complete capture of the reference (622 KB of text, 835 discarded groups, 8 sweeps) through the batched path:
+    counters and kept rows as the reference's functions gave them, the mean matrix and the blurred matrix of its
+    heatmap fixture, the tile from the reference's limits and colours."""
+    import hashlib
+    from slamhip.batch import process_texts
+    from slamhip.pipeline import default_mapping, viridis_lut
+    z = np.load(os.path.join(GOLDEN, "full_164520_text.npz"))
+    hz = np.load(os.path.join(GOLDEN, "heatmap_full_164520.npz"))
+    mapping, lut = default_mapping(), viridis_lut()
+    r = process_texts([z["text"].tobytes()], tile=256)[0]
+    st = r["stats"]
+    assert int(st[1]) == 0                                                    # strict capture format: single pass
+    assert (int(st[2]), int(st[3]), int(st[4]), int(st[5]), int(st[6])) == tuple(int(z[k]) for k in ("valid", "discarded", "groups", "baselines", "kept"))
+    kept = np.ascontiguousarray(np.stack([r["kept"][k].astype(np.int64) for k in ("ue", "bs", "rss", "clk")], 1))
+    assert hashlib.sha256(kept.tobytes()).hexdigest() == str(z["kept_sha256"])
+    rows = np.flatnonzero(np.isfinite(r["matrix"]).any(axis=1))
+    cols = np.flatnonzero(np.isfinite(r["matrix"]).any(axis=0))
+    assert np.array_equal(r["matrix"][np.ix_(rows, cols)], hz["matrix"], equal_nan=True)
+    assert r["aod"].tolist() == hz["aod"].tolist() and r["aoa"].tolist() == hz["aoa"].tolist()
+    fin = np.isfinite(hz["blurred"])
+    assert np.array_equal(np.isfinite(r["blurred"]), fin)
+    assert np.max(np.abs(r["blurred"][fin] - hz["blurred"][fin]) / np.abs(hz["blurred"][fin])) <= 1e-12
+    assert abs(r["vmin"] - float(hz["vmin"])) <= 1e-12 * abs(float(hz["vmin"]))      # the blur's last bits (tap order)
+    assert abs(r["vmax"] - float(hz["vmax"])) <= 1e-12 * abs(float(hz["vmax"]))
+    rr = O.render(r["blurred"], hz["aod"], hz["aoa"], lut, use_log=False, blur_sigma=0.0, W=256, H=256)
+    assert (r["vmin"], r["vmax"]) == (rr["vmin"], rr["vmax"]) and np.array_equal(r["tile"], rr["tile"])
+    # the reference's figure itself: its mesh colours sampled from the saved PNG (cells under the dashed grid aside)
+    cells = np.array([[rr["cells"][i, j] for j in range(rr["cells"].shape[1])] for i in range(rr["cells"].shape[0])])
+    same = (cells[..., :3].astype(int) == hz["cells_png"][..., :3].astype(int)).all(axis=2)
+    assert same.mean() > 0.9

@@ -193,3 +193,20 @@ def test_oracle_colour_limits_match_the_reference_figure():
         r = O.render(mat, e["aod"], e["aoa"], lut, use_log=e["use_log"], vmin=e["vmin_in"], vmax=e["vmax_in"], blur_sigma=0.0, W=8, H=8)
         assert (r["vmin"], r["vmax"]) == (e["vmin"], e["vmax"]), k
         assert np.array_equal(r["cells"].astype(int), np.array(e["cells"])), k
+
+
+def test_oracle_on_a_complete_capture():
+    """The smallest complete capture of the reference (622 KB of text, 8 groups, 414 baselines): counters and kept rows
+    as the reference's functions gave them, pivot sums as in its heatmap fixture."""
+    import hashlib
+    z = np.load(os.path.join(GOLDEN, "full_164520_text.npz"))
+    rows, v, d = O.parse_groups(O.read_bytes(z["text"].tobytes()))
+    assert (v, d) == (int(z["valid"]), int(z["discarded"]))
+    kept, ng, nb = O.filter_corrected(rows["flag"], rows["ue"], rows["bs"], rows["rss"], rows["clk"])
+    assert (ng, nb, len(kept["ue"])) == (int(z["groups"]), int(z["baselines"]), int(z["kept"]))
+    arr = np.ascontiguousarray(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1).astype(np.int64))
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == str(z["kept_sha256"])
+    mapping = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"], mapping)
+    hz = np.load(os.path.join(GOLDEN, "heatmap_full_164520.npz"))
+    assert np.array_equal(mat, hz["matrix"], equal_nan=True)
