@@ -835,3 +835,18 @@ def test_pivot_values_outside_the_packed_accumulators_room(ops, mapping):
     want = np.where(co > 0, so / np.maximum(co, 1), np.nan)
     assert int((k["rss"] >= 2 ** 27).sum()) > 100
     assert np.array_equal(full, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("sigma", [0.2, 0.5, 1.0, 3.0, 5.0])
+def test_blur_wide_and_narrow_kernels(ops, sigma):
+    """slam_blur_nan on small and non-square matrices with holes, from a 3 x 3 kernel to one wider than the matrix."""
+    rng = np.random.default_rng(8)
+    for shape in ((1, 1), (1, 9), (3, 3), (5, 12), (17, 4), (64, 64)):
+        m = rng.integers(15000, 93000, shape).astype(np.float64)
+        m[rng.random(shape) < 0.3] = np.nan
+        got = ops.blur_nan(m, sigma)
+        want = O.blur_nan_aware(m, sigma)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), shape
+        fin = np.isfinite(want)
+        if fin.any():
+            assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) <= REL, shape

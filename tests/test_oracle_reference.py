@@ -107,3 +107,26 @@ def test_reference_functions_on_a_synthetic_frame(ref, tmp_path):
     kept, ng, nb = O.filter_corrected(*arr.T)
     assert ng == int(df["_gid"].max()) + 1 == 8
     assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), res)
+
+
+def test_blur_against_the_reference_for_wide_and_narrow_kernels():
+    """gaussian_blur_nan_aware of the reference on small, non-square matrices with holes, kernels from 3 x 3 to wider
+    than the matrix (edge padding repeats the border) against the oracle's restatement."""
+    import importlib.util
+    import matplotlib
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("ref_excel_heatmap_v3_blur", os.path.join(REFERENCE, "excel_heatmap_v3.py"))
+    E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E)
+    rng = np.random.default_rng(8)
+    for shape in ((1, 1), (1, 9), (3, 3), (5, 12), (17, 4)):
+        for sigma in (0.2, 0.5, 1.0, 3.0, 5.0):
+            m = rng.integers(15000, 93000, shape).astype(np.float64)
+            m[rng.random(shape) < 0.3] = np.nan
+            want = E.gaussian_blur_nan_aware(m.copy(), sigma)
+            got = O.blur_nan_aware(m, sigma)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (shape, sigma)
+            fin = np.isfinite(want)
+            if fin.any():
+                assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) <= 1e-13, (shape, sigma)
+            assert np.allclose(O.gaussian_kernel(sigma), E.gaussian_kernel(sigma), rtol=1e-15, atol=0)
