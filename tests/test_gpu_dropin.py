@@ -572,3 +572,45 @@ def test_complete_capture_end_to_end():
     cells = np.array([[rr["cells"][i, j] for j in range(rr["cells"].shape[1])] for i in range(rr["cells"].shape[0])])
     same = (cells[..., :3].astype(int) == hz["cells_png"][..., :3].astype(int)).all(axis=2)
     assert same.mean() > 0.9
+
+
+def test_empty_cells_fuzz_against_the_oracle():
+    """Random tables with a few empty cells each, both drivers' data paths in memory, against the oracle's literal
+    restatement of the null rules (itself pinned on the reference by null_tables.json)."""
+    import pandas as pd
+    import bs_beam_correction as B
+    import serial_hex_to_excel_v3 as S
+    rng = np.random.default_rng(404)
+    logging.disable(logging.CRITICAL)
+    try:
+        outcomes = {"ok": 0, "ValueError": 0}
+        for trial in range(250):
+            n_groups = int(rng.integers(1, 5))
+            rows = []
+            for g in range(n_groups):
+                n = int(rng.integers(2, 18))
+                c0 = int(rng.integers(1_000_000, 50_000_000))
+                rss = int(rng.integers(15000, 90000))
+                for i in range(n):
+                    fl = int(rng.random() < 0.25)
+                    if not fl or rng.random() < 0.5:
+                        rss = int(rng.integers(15000, 90000)) if rng.random() < 0.6 else rss
+                    rows.append([fl, min(63, i * 64 // n), int(rng.integers(0, 64)), rss,
+                                 c0 + i * B.CYCLE + int(rng.integers(-700, 700))])
+            for _ in range(int(rng.integers(1, 5))):
+                rows[int(rng.integers(0, len(rows)))][int(rng.integers(0, 5))] = None
+            for filtered in (True, False):
+                gid, want = O.correct_table_nulls_py(rows, filtered)
+                df = B._coerce_types(pd.DataFrame(dict(zip(S.HEADER, [list(c) for c in zip(*rows)]))))
+                assert B._detect_groups(df).tolist() == gid, trial
+                try:
+                    got = B._correct_frame(df, filtered)
+                    got = got.to_numpy().tolist() if filtered else [int(v) for v in got.tolist()]
+                    assert "error" not in want and got == want["result"], (trial, filtered)
+                    outcomes["ok"] += 1
+                except ValueError as ex:
+                    assert want.get("error") == "ValueError" and str(ex) == want["message"], (trial, filtered, str(ex))
+                    outcomes["ValueError"] += 1
+        assert outcomes["ok"] > 100 and outcomes["ValueError"] > 50, outcomes
+    finally:
+        logging.disable(logging.NOTSET)

@@ -130,3 +130,51 @@ def test_blur_against_the_reference_for_wide_and_narrow_kernels():
             if fin.any():
                 assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) <= 1e-13, (shape, sigma)
             assert np.allclose(O.gaussian_kernel(sigma), E.gaussian_kernel(sigma), rtol=1e-15, atol=0)
+
+
+def test_null_rules_fuzz_against_the_reference():
+    """The oracle's restatement of the empty-cell rules against the reference's own drivers on 200 random tables
+    (the same generator the GPU fuzz uses): result rows, Corrected_BS_Beam column or the exception's text."""
+    import importlib.util
+    import pandas as pd
+    spec = importlib.util.spec_from_file_location("ref_bs_beam_correction_nullfuzz", os.path.join(REFERENCE, "bs_beam_correction.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    cols = [B.FLAG_COL, B.UE_BEAM_COL, B.BS_BEAM_COL, B.RSS_COL, B.CLK_COL]
+    rng = np.random.default_rng(404)
+
+    def reference(rows, filtered):
+        df = B._coerce_types(pd.DataFrame([[np.nan if v is None else v for v in r] for r in rows], columns=cols, dtype=object))
+        gid = B._detect_groups(df)
+        df["_gid"] = gid
+        try:
+            pieces = []
+            for g, sub in df.groupby("_gid", sort=True):
+                out = (B._filter_group_corrected if filtered else B._correct_group)(sub, B._identify_baselines(sub))
+                if not filtered or not out.empty:
+                    pieces.append(out)
+            if filtered:
+                if not pieces:
+                    raise ValueError("未产生任何可修正数据行，输出为空")
+                res = pd.concat(pieces, ignore_index=True)
+                return gid.tolist(), dict(result=[[int(v) for v in r] for r in res.to_numpy().tolist()])
+            res = pd.concat(pieces).sort_index()
+            return gid.tolist(), dict(result=[int(v) for v in res[B.OUT_COL].tolist()])
+        except ValueError as ex:
+            return gid.tolist(), dict(error="ValueError", message=str(ex))
+
+    for trial in range(200):
+        rows = []
+        for g in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(2, 18))
+            c0 = int(rng.integers(1_000_000, 50_000_000))
+            rss = int(rng.integers(15000, 90000))
+            for i in range(n):
+                fl = int(rng.random() < 0.25)
+                if not fl or rng.random() < 0.5:
+                    rss = int(rng.integers(15000, 90000)) if rng.random() < 0.6 else rss
+                rows.append([fl, min(63, i * 64 // n), int(rng.integers(0, 64)), rss, c0 + i * B.CYCLE + int(rng.integers(-700, 700))])
+        for _ in range(int(rng.integers(1, 5))):
+            rows[int(rng.integers(0, len(rows)))][int(rng.integers(0, 5))] = None
+        for filtered in (True, False):
+            assert O.correct_table_nulls_py(rows, filtered) == reference(rows, filtered), (trial, filtered)
