@@ -124,7 +124,8 @@ int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const i
 
 /* ---- a11-a12: NaN-aware Gaussian blur --------------------------------------------------------------
  * Replaces gaussian_kernel (:320-333) + gaussian_blur_nan_aware (:336-368): normalised
- * convolution, edge padding, NaN where the weight sum <= 1e-12.  h, w <= 256.  sigma <= 0 copies. */
+ * convolution, edge padding, NaN where the weight sum <= 1e-12.  h, w <= 4096; kernels of up to 127 taps
+ * (sigma <= 21), SLAM_E_RANGE beyond.  sigma <= 0 copies. */
 int slam_blur_nan(slam_ctx *ctx, const double *in, int h, int w, double sigma, double *out);
 
 /* ---- a13: colour scale + mesh raster --------------------------------------------------------------
@@ -150,7 +151,8 @@ typedef struct slam_batch {
     const uint64_t *text_off_dev; /* [F] byte offset of each frame's text                        */
     const uint32_t *text_len_dev; /* [F] text bytes of each frame                                */
     uint32_t n_frames;            /* F, at most 65535 per call                                    */
-    uint32_t max_text_len;        /* max over frames of text_len (host-known upper bound)        */
+    uint32_t max_text_len;        /* max over frames of text_len (host-known upper bound; a frame */
+                                  /* whose length word is larger is cut at this many bytes)       */
     uint32_t src_is_bytes;        /* 0: text_dev holds hex text in the capture format;            */
                                   /* 1: it holds already-unpacked data bytes (slam_hex_unpack)    */
     int32_t cycle, tol, mod_base; /* CYCLE, TOL, MOD_BASE (bs_beam_correction.py:23-25)          */

@@ -118,6 +118,10 @@ static int get_kernel(slam_ctx *ctx, double sigma, double **kern, int *ks)
     constexpr int KMAX = 127;
     if (!ctx->kern_dev) SLAM_HIP(ctx, hipMalloc((void **)&ctx->kern_dev, KMAX * KMAX * sizeof(double)));
     if (ctx->kern_size == 0 || ctx->kern_sigma != sigma) {
+        // the size is checked before the kernel is built: size * size doubles for an arbitrary sigma is unbounded
+        if (sigma != sigma) return slam_fail(ctx, SLAM_E_INVALID, "blur sigma is NaN");
+        if (sigma > 0 && ceil(6.0 * sigma) > (double)KMAX)
+            return slam_fail(ctx, SLAM_E_RANGE, "blur sigma %.3f needs a %.0f-tap kernel (max %d)", sigma, ceil(6.0 * sigma), KMAX);
         std::vector<double> k;
         int size = slam_gaussian_kernel_host(sigma, k);
         if (size > KMAX) return slam_fail(ctx, SLAM_E_RANGE, "blur sigma %.3f needs a %d-tap kernel (max %d)", sigma, size, KMAX);
@@ -146,9 +150,13 @@ int slam_timer_begin(slam_ctx *ctx, const char *name)
     }
     slam_ctx::pending_ev p;
     p.slot = slot;
+    p.a = p.b = nullptr;
     for (hipEvent_t *e : {&p.a, &p.b}) {
         if (!ctx->ev_pool.empty()) { *e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
-        else if (hipEventCreate(e) != hipSuccess) return -1;
+        else if (hipEventCreate(e) != hipSuccess) {
+            if (p.a) ctx->ev_pool.push_back(p.a);          // the launch goes untimed; nothing is lost
+            return -1;
+        }
     }
     (void)hipEventRecord(p.a, ctx->stream);
     ctx->pending.push_back(p);
@@ -500,6 +508,7 @@ extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *u
     const bool explicit_bl = bl_in_n >= 0;
     if (explicit_bl && bl_in_n > 0 && (!bl_in_clk || !bl_in_bs))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_correct: null baseline arrays");
+    if (bl_in_n > 0x7FFFFF00ll) return slam_fail(ctx, SLAM_E_RANGE, "too many baselines");
     for (size_t i = 0; i < n; i++)
         if (clk[i] <= -(1 << 30) || clk[i] >= (1 << 30))
             return slam_fail(ctx, SLAM_E_RANGE, "clk[%zu] = %d is outside (-2^30, 2^30)", i, clk[i]);
@@ -572,6 +581,10 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     if (!beam_to_axis || n_axis < 1 || n_axis > 64) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: bad axis table");
     if (n && (!ue || !bs || !rss)) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: null column");
     if (n > 0x7FFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "too many rows");
+    for (int i = 0; i < 64; i++)
+        if (beam_to_axis[i] >= n_axis)
+            return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: beam_to_axis[%d] = %d is not below n_axis = %d", i,
+                             beam_to_axis[i], n_axis);
     const uint32_t row_cap = round16(n + 16);
     const int cells = n_axis * n_axis;
     ws_plan p;
@@ -686,6 +699,8 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: text, offsets, lengths and stats are required");
     if (bt->n_frames > 65535u)          // frames are the y (z for the raster) dimension of the launch grids
         return slam_fail(ctx, SLAM_E_RANGE, "slam_batch: at most 65535 frames per call, got %u", bt->n_frames);
+    if (bt->tile_dev && (bt->tile_w < 1 || bt->tile_h < 1))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: tile of %d x %d", bt->tile_w, bt->tile_h);
     if (bt->tile_dev && (int64_t)bt->tile_h > 16 * 65535ll)
         return slam_fail(ctx, SLAM_E_RANGE, "slam_batch: tile of %d x %d is beyond the raster kernel's grid", bt->tile_w, bt->tile_h);
     bp.st_max = slot_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);

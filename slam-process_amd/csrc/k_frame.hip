@@ -47,12 +47,14 @@ struct src_view {
 // instead of a chain of dependent reads (offset table -> text prefix).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_frame_prepare(frame_src s, uint32_t F, frame_desc *fd, uint32_t *stats,
-                                                        int slotted, int force_two_pass)
+                                                        int slotted, int force_two_pass, uint32_t max_len)
 {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
     const uint8_t *p = s.base + s.off[f];
-    const uint32_t n = s.len[f];
+    // Grids, tile tables and row arrays are sized from the caller's bound: a frame whose length word exceeds it is
+    // cut there rather than trusted.
+    const uint32_t n = min(s.len[f], max_len);
     frame_desc d;
     bool bad = false;
     if (MODE == SRC_TEXT3) {
@@ -899,10 +901,10 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, u
     const int force = slotted && force_env && force_env[0] == '1';
     if (mode == SRC_TEXT3) {
         SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_TEXT3>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc,
-                    stats, slotted, force);
+                    stats, slotted, force, max_src_len);
     } else {
         SLAM_LAUNCH(ctx, "frame_prepare", (k_frame_prepare<SRC_RAW>), dim3((F + 255) / 256), dim3(256), src, F, ws.fdesc,
-                    stats, slotted, force);
+                    stats, slotted, force, max_src_len);
     }
     if (slotted) {
         const uint32_t st_max = slot_tiles_for(mode, max_src_len);

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
                 if (i0 + k >= lim[h]) break;
                 if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
                 int c = b2a[uu[k]], rw = b2a[bb[k]];
-                if (c < 0 || rw < 0) continue;                                       // unmapped beam dropped (:275)
+                // unmapped beam (-1) dropped (:275); an index at or past n_axis cannot come from a valid table
+                if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
                 if (rr[k] >= 0 && rr[k] < ROW_LIMIT) {
                     atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << SHIFT));
                 } else {                                                             // no room in the packed sum

@@ -761,7 +761,9 @@ def test_batched_api_rejects_bad_arguments(mapping, lut):
     pipe = FramePipeline(F, tl, tile_w=64, tile_h=64, mapping=mapping, lut=lut)
     pipe.set_uniform_layout(F, stride, tl)
     pipe.run(text)                                           # the untouched batch works
-    good = {k: getattr(pipe.bt, k) for k in ("row_cap", "flag_dev", "lut_dev", "cycle", "n_frames", "tile_h")}
+    good = {k: getattr(pipe.bt, k) for k in ("row_cap", "flag_dev", "lut_dev", "cycle", "n_frames", "tile_h", "tile_w",
+                                             "blur_sigma")}
+    st_good = pipe.stats_host().copy()
 
     def expect_error(field, value, code):
         setattr(pipe.bt, field, value)
@@ -780,9 +782,20 @@ def test_batched_api_rejects_bad_arguments(mapping, lut):
     expect_error("cycle", (1 << 30) + 1, _lib.E_INVALID)
     expect_error("n_frames", 65536, _lib.E_RANGE)                          # frames ride on a grid dimension
     expect_error("tile_h", 16 * 65535 + 1, _lib.E_RANGE)
+    expect_error("tile_w", -1, _lib.E_INVALID)
+    expect_error("tile_h", 0, _lib.E_INVALID)
+    expect_error("blur_sigma", float("nan"), _lib.E_INVALID)
+    expect_error("blur_sigma", 1e9, _lib.E_RANGE)            # refused before a kernel of 6e9 taps a side is built
+    expect_error("blur_sigma", 21.5, _lib.E_RANGE)
     pipe.run(text)                                           # and still works afterwards
     st = pipe.stats_host()
     assert int(st[0, 2]) > 0 and int(st[0, 6]) > 0
+    # a length word beyond the batch's stated bound is cut at the bound, not trusted: the frame's text is exactly that
+    # long here, so every counter comes out as before
+    pipe.len[1:2] = 0x7FFFFFF0
+    pipe.run(text)
+    assert np.array_equal(pipe.stats_host(), st_good)
+    pipe.len[1:2] = tl
 
 
 def test_skipped_token_lines_follow_the_reference(ops):
@@ -850,3 +863,25 @@ def test_blur_wide_and_narrow_kernels(ops, sigma):
         fin = np.isfinite(want)
         if fin.any():
             assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) <= REL, shape
+
+
+def test_host_entry_points_refuse_what_they_cannot_run(ops, mapping):
+    """Arguments that would index outside a kernel's tables or size a host buffer without bound come back as error
+    codes: an axis table that points past n_axis, a NaN sigma, a sigma whose kernel exceeds the device table."""
+    from slamhip import _lib
+    b2a, angles = ops.axis_from_mapping(mapping)
+    bad = b2a.copy()
+    bad[5] = len(angles)
+    col = np.arange(64)
+    with pytest.raises(_lib.SlamError) as ei:
+        ops.pivot_mean(col, col, col + 20000, bad, len(angles))
+    assert ei.value.code == _lib.E_INVALID and "beam_to_axis[5]" in ei.value.msg
+    s, c, m = ops.pivot_mean(col, col, col + 20000, b2a, len(angles))          # the valid table still works
+    assert int(c.sum()) == int((b2a >= 0).sum())
+    data = np.arange(12.0).reshape(3, 4)
+    for sigma, code in ((float("nan"), _lib.E_INVALID), (1e9, _lib.E_RANGE), (21.5, _lib.E_RANGE)):
+        with pytest.raises(_lib.SlamError) as ei:
+            ops.blur_nan(data, sigma)
+        assert ei.value.code == code, sigma
+    assert ops.blur_nan(data, 21.0).shape == (3, 4)                            # 127 taps, the largest kernel
+    assert np.array_equal(ops.blur_nan(data, -1.0), data)
