@@ -92,6 +92,30 @@ def cpu_baseline(B, N, n_frames, tile):
                        f"({sum(r['dt'] for r in res):.0f} core-seconds)")
 
 
+def measured_ceilings(ctx, pipe, achieved_gbs):
+    """What this device sustains on plain streams, by the library's probe kernels and the same HIP-event timers as the
+    pipeline's kernels: read-only, copy 1:1, and read 3 : write 1 (the framing kernel's mix).  Runs after every
+    result has been read back: it streams over the tile and kept-row buffers and leaves them overwritten."""
+    import ctypes as C
+    src, dst = pipe.tiles.view(-1), pipe.k_rss.view(torch.uint8).view(-1)
+    n = min(src.numel(), dst.numel(), 4 << 30) // 4096 * 4096
+    if n < (64 << 20):
+        return None
+    sp, dp = C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr())
+    ctx.timing_reset()
+    ctx.timing(True)
+    for _ in range(6):
+        ctx.check(ctx.lib.slam_copy_probe_dev(ctx.h, sp, sp, n))            # same pointer: read-only stream
+        ctx.check(ctx.lib.slam_copy_probe_dev(ctx.h, dp, sp, n))
+        ctx.check(ctx.lib.slam_read_probe_dev(ctx.h, dp, sp, n, 20))
+    ctx.timing(False)
+    t = ctx.timing_read()
+    gbs = lambda name, nbytes: round(nbytes / (t[name][1] / t[name][0] * 1e-3) / 1e9, 1)      # noqa: E731
+    mix = gbs("mix3_0", n + n // 3)
+    return dict(read_GBps=gbs("read_probe", n), copy_GBps=gbs("copy_probe", 2 * n), read3_write1_GBps=mix,
+                probe_bytes=n, frac_of_read3_write1=round(achieved_gbs / mix, 4))
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -282,6 +306,9 @@ def main():
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                     alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
+
+    if roof is not None and rank == 0:
+        roof["measured_ceilings"] = measured_ceilings(ctx, pipe, ach)
 
     out = {
         "metric": "frames/s (256-beam x 4096-sample decode+correct+raster)",
