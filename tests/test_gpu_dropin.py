@@ -614,3 +614,29 @@ def test_empty_cells_fuzz_against_the_oracle():
         assert outcomes["ok"] > 100 and outcomes["ValueError"] > 50, outcomes
     finally:
         logging.disable(logging.NOTSET)
+
+
+def test_every_capture_of_the_reference_as_one_ragged_batch():
+    """All 19 capture logs of the reference (36 MB of text, 0.6 to 3.3 MB each) in one batched call: per capture the
+    counters, decoded rows, kept rows and mean matrix exactly as the reference's own functions gave them
+    (tests/golden/captures_all.npz), its blurred matrix to 1e-12."""
+    import hashlib
+    from test_oracle_golden import load_all_captures
+    from slamhip.batch import process_texts
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()      # noqa: E731
+    caps = load_all_captures()
+    res = process_texts([t for _, t, _ in caps], tile=64)
+    assert len(res) == 19
+    for (e, text, blurred), r in zip(caps, res):
+        st = r["stats"]
+        assert int(st[1]) == 0, e["name"]                                     # strict capture format: single pass
+        assert tuple(int(st[k]) for k in (2, 3, 4, 5, 6)) == (e["valid"], e["discarded"], e["groups"], e["baselines"], e["kept"]), e["name"]
+        assert sha(np.stack([r["rows"][k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1)) == e["rows_sha256"]
+        assert sha(np.stack([r["kept"][k].astype(np.int64) for k in ("ue", "bs", "rss", "clk")], 1)) == e["kept_sha256"]
+        rows = np.flatnonzero(np.isfinite(r["matrix"]).any(axis=1))
+        cols = np.flatnonzero(np.isfinite(r["matrix"]).any(axis=0))
+        assert sha(r["matrix"][np.ix_(rows, cols)].astype(np.float64)) == e["matrix_sha256"], e["name"]
+        assert r["aod"].tolist() == e["aod"] and r["aoa"].tolist() == e["aoa"]
+        fin = np.isfinite(blurred)
+        assert np.array_equal(np.isfinite(r["blurred"]), fin), e["name"]
+        assert np.max(np.abs(r["blurred"][fin] - blurred[fin]) / np.abs(blurred[fin])) <= 1e-12, e["name"]

@@ -210,3 +210,42 @@ def test_oracle_on_a_complete_capture():
     mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"], mapping)
     hz = np.load(os.path.join(GOLDEN, "heatmap_full_164520.npz"))
     assert np.array_equal(mat, hz["matrix"], equal_nan=True)
+
+
+def load_all_captures():
+    """(index entry, text bytes, reference's blurred matrix) per capture of tests/golden/captures_all.npz; the text is
+    rebuilt from the stored data bytes and checked against the digest of the reference's file."""
+    import hashlib
+    import lzma
+    z = np.load(os.path.join(GOLDEN, "captures_all.npz"))
+    index = json.loads(z["index"].tobytes().decode("utf-8"))
+    out = []
+    for i, e in enumerate(index):
+        data = lzma.decompress(z[f"data_{i}"].tobytes())
+        text = "« ".encode("utf-8") + "".join(f"{b:02X} " for b in data).encode("ascii")
+        assert len(text) == e["n_text"] and hashlib.sha256(text).hexdigest() == e["text_sha256"], e["name"]
+        out.append((e, text, z[f"blurred_{i}"]))
+    return out
+
+
+def test_oracle_on_every_capture_of_the_reference():
+    """All 19 capture logs: counters, decoded rows, kept rows and the mean matrix exactly as the reference's own
+    functions gave them (digests), its blurred matrix to the last bits."""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()      # noqa: E731
+    mapping = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    caps = load_all_captures()
+    assert len(caps) == 19
+    for e, text, blurred in caps:
+        rows, v, d = O.parse_groups(O.read_bytes(text))
+        assert (v, d) == (e["valid"], e["discarded"]), e["name"]
+        assert sha(np.stack([rows[k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1)) == e["rows_sha256"]
+        kept, ng, nb = O.filter_corrected(rows["flag"], rows["ue"], rows["bs"], rows["rss"], rows["clk"])
+        assert (ng, nb, len(kept["ue"])) == (e["groups"], e["baselines"], e["kept"]), e["name"]
+        assert sha(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1).astype(np.int64)) == e["kept_sha256"]
+        mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"], mapping)
+        assert list(aod) == e["aod"] and list(aoa) == e["aoa"] and sha(mat.astype(np.float64)) == e["matrix_sha256"]
+        mine = O.blur_nan_aware(mat, 1.0)
+        fin = np.isfinite(blurred)
+        assert np.array_equal(np.isfinite(mine), fin)
+        assert np.max(np.abs(mine[fin] - blurred[fin]) / np.abs(blurred[fin])) <= 1e-14, e["name"]
