@@ -59,9 +59,11 @@ def main(argv=None) -> int:
     mine = D.balance_files([os.path.getsize(p) for p in paths], world)[rank]
     for i, r in zip(mine, res):
         st = r["stats"]
-        print(json.dumps(dict(log=paths[i], rank=rank, valid=int(st[_lib.STAT_VALID]), discarded=int(st[_lib.STAT_DISCARDED]),
-                              groups=int(st[_lib.STAT_GROUPS]), baselines=int(st[_lib.STAT_BASELINES]),
-                              kept=int(st[_lib.STAT_KEPT]), grid=[len(r["aod"]), len(r["aoa"])]), ensure_ascii=False), flush=True)
+        line = json.dumps(dict(log=paths[i], rank=rank, valid=int(st[_lib.STAT_VALID]), discarded=int(st[_lib.STAT_DISCARDED]),
+                               groups=int(st[_lib.STAT_GROUPS]), baselines=int(st[_lib.STAT_BASELINES]),
+                               kept=int(st[_lib.STAT_KEPT]), grid=[len(r["aod"]), len(r["aoa"])]), ensure_ascii=False)
+        sys.stdout.write(line + "\n")          # one write per line: the ranks share the launcher's pipe
+        sys.stdout.flush()
     if rank == 0:
         for p, t in zip(paths, tiles):
             d = a.out_dir or os.path.join(os.path.dirname(os.path.abspath(p)), "heatmap_outputs")

@@ -640,3 +640,43 @@ def test_every_capture_of_the_reference_as_one_ragged_batch():
         fin = np.isfinite(blurred)
         assert np.array_equal(np.isfinite(r["blurred"]), fin), e["name"]
         assert np.max(np.abs(r["blurred"][fin] - blurred[fin]) / np.abs(blurred[fin])) <= 1e-12, e["name"]
+
+
+def test_batch_driver_every_capture_over_four_ranks(tmp_path):
+    """BASELINE's third configuration in small: all 19 capture logs of the reference under their own file names, the
+    driver under torch.distributed with four ranks (sharing this GPU, gloo collectives through the host).  Files are
+    balanced over the ranks by size, every log's summary line carries the reference's counters, and rank 0 writes
+    every tile: the bytes the single-process batch renders."""
+    import socket
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import PKG
+    from test_oracle_golden import load_all_captures
+    from slamhip.batch import process_texts
+    caps = load_all_captures()
+    logs = tmp_path / "debugDoc"
+    logs.mkdir()
+    for e, text, _ in caps:
+        (logs / e["name"]).write_bytes(text)
+    out = tmp_path / "tiles"
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "slamhip.run_logs", str(logs), "--out-dir", str(out), "--tile", "128",
+           "--backend", "gloo"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = {os.path.basename(ln["log"]): ln for ln in (json.loads(s) for s in p.stdout.splitlines() if s.startswith("{"))}
+    assert sorted(lines) == sorted(e["name"] for e, _, _ in caps)
+    assert {ln["rank"] for ln in lines.values()} == {0, 1, 2, 3}
+    per_rank = [sum(e["n_text"] for e, _, _ in caps if lines[e["name"]]["rank"] == r) for r in range(4)]
+    assert max(per_rank) < 1.25 * min(per_rank), per_rank                     # balanced by size
+    want = process_texts([t for _, t, _ in caps], tile=128)
+    for (e, _, _), r in zip(caps, want):
+        ln = lines[e["name"]]
+        assert (ln["valid"], ln["discarded"], ln["kept"]) == (e["valid"], e["discarded"], e["kept"]), e["name"]
+        assert ln["grid"] == [len(e["aod"]), len(e["aoa"])]
+        assert np.array_equal(np.asarray(Image.open(out / (e["name"][:-4] + "_tile.png"))), r["tile"]), e["name"]
