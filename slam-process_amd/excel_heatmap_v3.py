@@ -293,23 +293,19 @@ def process_excel_to_heatmap(input_path: str, map_path: str, output_path: Option
                              vmax: Optional[float] = None, blur_sigma: float = 0.0,
                              logger: Optional[logging.Logger] = None) -> str:
     """read -> validate -> map -> pivot -> draw; returns the PNG path (reference :481-552)."""
-    ts = datetime.now().strftime("%Y%m%d_%H%M%S")
-    log_dir = os.path.dirname(output_path) if output_path else os.path.dirname(input_path)
-    lg = logger or setup_logger(os.path.join(log_dir, f"excel_heatmap_{ts}.log"))
+    where = os.path.dirname(output_path or input_path)
+    lg = logger or setup_logger(os.path.join(where, "excel_heatmap_%s.log" % datetime.now().strftime("%Y%m%d_%H%M%S")))
     try:
-        lg.info("====== 开始处理Excel数据并生成热力图 ======")
-        lg.info(f"主数据文件: {input_path}")
-        lg.info(f"映射文件: {map_path}")
-        df_main = read_main_data(input_path=input_path, sheet_name=sheet_name_main, logger=lg)
-        mapping = read_mapping(map_path=map_path, sheet_name=sheet_name_map, logger=lg)
-        df_mapped = map_angles(df_main, mapping, logger=lg)
-        matrix, aod_list, aoa_list = compute_rssi_matrix(df_mapped, logger=lg)
-        if output_path is None or output_path.strip() == "":
-            base = os.path.splitext(os.path.basename(input_path))[0]
-            output_path = os.path.join(os.path.dirname(input_path), "heatmap_outputs", f"{base}_heatmap.png")
-        title = f"BS-UE 波束对平均RSSI热力图 ({os.path.basename(input_path)})"
-        generate_heatmap(matrix=matrix, aod_list=aod_list, aoa_list=aoa_list, output_path=output_path, title=title,
-                         colormap=colormap, use_log=use_log, vmin=vmin, vmax=vmax, blur_sigma=blur_sigma, logger=lg)
+        for line in ("====== 开始处理Excel数据并生成热力图 ======", f"主数据文件: {input_path}", f"映射文件: {map_path}"):
+            lg.info(line)
+        rows = read_main_data(input_path=input_path, sheet_name=sheet_name_main, logger=lg)
+        rows = map_angles(rows, read_mapping(map_path=map_path, sheet_name=sheet_name_map, logger=lg), logger=lg)
+        grid = compute_rssi_matrix(rows, logger=lg)
+        name = os.path.basename(input_path)
+        if not (output_path or "").strip():
+            output_path = os.path.join(os.path.dirname(input_path), "heatmap_outputs", os.path.splitext(name)[0] + "_heatmap.png")
+        generate_heatmap(*grid, output_path, f"BS-UE 波束对平均RSSI热力图 ({name})", colormap, use_log, vmin, vmax,
+                         blur_sigma, lg)
         lg.info("====== 处理完成 ======")
         return output_path
     except Exception as e:
@@ -317,38 +313,43 @@ def process_excel_to_heatmap(input_path: str, map_path: str, output_path: Option
         raise
 
 
+# The reference's options with its defaults (:558-604); the help texts are this build's own wording.
+_OPTIONS = (
+    ("--input", str, r"D:\Code\SLAMPro\UE21\debugDoc\Serial Debug 2026-01-26 165358_filtered.xlsx", "修正后的主数据工作簿 (xlsx)"),
+    ("--mapping", str, r"D:\桌面\SLAMM\beam_angle.xlsx", "波束号到角度的对照工作簿 (xlsx)"),
+    ("--output", str, "", "PNG 输出位置；留空则写到主数据旁的 heatmap_outputs 目录"),
+    ("--sheet-main", str, None, "主数据所在工作表"),
+    ("--sheet-map", str, None, "对照表所在工作表"),
+    ("--colormap", str, "viridis", "matplotlib 色图名称"),
+    ("--vmin", float, None, "对数色标下限（线性色标不使用）"),
+    ("--vmax", float, None, "对数色标上限（线性色标不使用）"),
+    ("--blur-sigma", float, 1.0, "高斯平滑的 sigma，0 表示不平滑"),
+)
+
+
 def build_arg_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(description="读取Excel数据并生成BS-UE平均RSSI热力图（支持中文显示、日志、可选模糊）")
-    p.add_argument("--input", type=str,
-                   default=r"D:\Code\SLAMPro\UE21\debugDoc\Serial Debug 2026-01-26 165358_filtered.xlsx", help="主数据Excel路径")
-    p.add_argument("--mapping", type=str, default=r"D:\桌面\SLAMM\beam_angle.xlsx", help="BeamID->Angle映射Excel路径")
-    p.add_argument("--output", type=str, default="", help="输出PNG路径（默认与主数据同目录的heatmap_outputs下）")
-    p.add_argument("--sheet-main", type=str, default=None, help="主数据工作表名")
-    p.add_argument("--sheet-map", type=str, default=None, help="映射工作表名")
-    p.add_argument("--colormap", type=str, default="viridis", help="热力图风格（如: viridis, plasma, inferno, magma, jet 等）")
-    p.add_argument("--logscale", action="store_true", default=False, help="使用对数颜色标度（默认开启）")
-    p.add_argument("--vmin", type=float, default=None, help="颜色刻度最小RSSI（可选，默认自动）")
-    p.add_argument("--vmax", type=float, default=None, help="颜色刻度最大RSSI（可选，默认自动）")
-    p.add_argument("--blur-sigma", type=float, default=1.0, help="高斯模糊强度（0为不模糊）")
+    p = argparse.ArgumentParser(description="修正后的工作簿 -> BS/UE 波束对平均 RSSI 热力图 (GPU)")
+    for flag, kind, default, text in _OPTIONS:
+        p.add_argument(flag, type=kind, default=default, help=text)
+    p.add_argument("--logscale", action="store_true", default=False, help="改用对数色标")
     return p
 
 
 def main():
     args = build_arg_parser().parse_args()
-    ts = datetime.now().strftime("%Y%m%d_%H%M%S")
-    log_dir = (os.path.dirname(args.output) if args.output
-               else os.path.dirname(args.input) if os.path.isfile(args.input) else os.getcwd())
-    logger = setup_logger(os.path.join(log_dir, f"excel_heatmap_{ts}.log"))
-    logger.info(f"参数: input='{args.input}', mapping='{args.mapping}', output='{args.output}', "
-                f"sheet_main='{args.sheet_main}', sheet_map='{args.sheet_map}', colormap='{args.colormap}', "
-                f"logscale={args.logscale}, vmin={args.vmin}, vmax={args.vmax}, blur_sigma={args.blur_sigma}")
+    if args.output:
+        log_dir = os.path.dirname(args.output)
+    else:
+        log_dir = os.path.dirname(args.input) if os.path.isfile(args.input) else os.getcwd()
+    logger = setup_logger(os.path.join(log_dir, "excel_heatmap_%s.log" % datetime.now().strftime("%Y%m%d_%H%M%S")))
+    shown = [(k, getattr(args, k)) for k in ("input", "mapping", "output", "sheet_main", "sheet_map", "colormap",
+                                             "logscale", "vmin", "vmax", "blur_sigma")]
+    logger.info("参数: " + ", ".join(f"{k}={v}" if k in ("logscale", "vmin", "vmax", "blur_sigma") else f"{k}='{v}'"
+                                    for k, v in shown))
     try:
-        out_png = process_excel_to_heatmap(input_path=args.input, map_path=args.mapping,
-                                           output_path=args.output if args.output else None,
-                                           sheet_name_main=args.sheet_main, sheet_name_map=args.sheet_map,
-                                           colormap=args.colormap, use_log=args.logscale, vmin=args.vmin,
-                                           vmax=args.vmax, blur_sigma=args.blur_sigma, logger=logger)
-        logger.info(f"输出PNG: {out_png}")
+        png_path = process_excel_to_heatmap(args.input, args.mapping, args.output or None, args.sheet_main, args.sheet_map,
+                                            args.colormap, args.logscale, args.vmin, args.vmax, args.blur_sigma, logger)
+        logger.info(f"输出PNG: {png_path}")
     except Exception as e:
         logger.error(f"执行失败: {e}", exc_info=True)
         sys.exit(1)

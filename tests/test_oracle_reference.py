@@ -178,3 +178,27 @@ def test_null_rules_fuzz_against_the_reference():
             rows[int(rng.integers(0, len(rows)))][int(rng.integers(0, 5))] = None
         for filtered in (True, False):
             assert O.correct_table_nulls_py(rows, filtered) == reference(rows, filtered), (trial, filtered)
+
+
+def test_heatmap_command_line_options_equal_the_references():
+    """build_arg_parser of the drop-in against the reference's: the same options, destinations, types and defaults
+    (help texts are free), and the same '参数:' log line for one parsed command line."""
+    import importlib.util
+    import matplotlib
+    matplotlib.use("Agg")
+    from conftest import PKG
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    R = load(os.path.join(REFERENCE, "excel_heatmap_v3.py"), "ref_excel_heatmap_v3_cli")
+    M = load(os.path.join(PKG, "excel_heatmap_v3.py"), "own_excel_heatmap_v3_cli")
+
+    def options(parser):
+        return sorted((tuple(a.option_strings), a.dest, repr(a.default), getattr(a, "type", None), type(a).__name__, a.nargs)
+                      for a in parser._actions)
+
+    assert options(R.build_arg_parser()) == options(M.build_arg_parser())
