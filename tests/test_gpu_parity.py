@@ -885,3 +885,80 @@ def test_host_entry_points_refuse_what_they_cannot_run(ops, mapping):
         assert ei.value.code == code, sigma
     assert ops.blur_nan(data, 21.0).shape == (3, 4)                            # 127 taps, the largest kernel
     assert np.array_equal(ops.blur_nan(data, -1.0), data)
+
+
+def _grammar_stream(rng) -> bytes:
+    """A byte stream from a small grammar: sweeps of valid records (UE ramps, handovers that repeat the RSS of the row
+    before, clocks on and off the cycle grid), records with one byte damaged, stray flag bytes, noise, record-free
+    stretches; cut at a random place, often right around a tile edge."""
+    rec = lambda fl, ue, bs, clk, rss: bytes([0xCC if fl else 0x33, ue & 63, 0xC0 | (bs & 63)] +      # noqa: E731
+                                             [0x40 | ((clk >> (6 * j)) & 63) for j in range(5)] +
+                                             [0x80 | ((rss >> (6 * j)) & 63) for j in range(3)])
+    out = bytearray()
+    want = int(rng.choice([0, 5, 40, 300, 3024, 6048, 9072, 15000])) + int(rng.integers(0, 3100))
+    clk, rss = int(rng.integers(1000, 10 ** 6)), 20000
+    while len(out) < want:
+        kind = rng.random()
+        if kind < 0.70:                                   # a stretch of one sweep
+            n = int(rng.integers(1, 400))
+            span = int(rng.integers(1, 2000))
+            for i in range(n):
+                handover = rng.random() < 0.05
+                if not handover:
+                    rss = int(rng.integers(15000, 93000))
+                clk = (clk + 61000 + (int(rng.integers(-600, 600)) if rng.random() < 0.5 else 0)) % (1 << 30)
+                r = bytearray(rec(handover, min(63, i * 64 // span), int(rng.integers(0, 64)), clk, rss))
+                if rng.random() < 0.02:
+                    r[int(rng.integers(0, 11))] = int(rng.integers(0, 256))
+                out += r
+        elif kind < 0.80:
+            out += bytes(rng.choice(np.frombuffer(b"\x33\xcc", np.uint8), int(rng.integers(1, 40))))
+        elif kind < 0.90:
+            out += bytes(rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8))
+        elif kind < 0.95:
+            out += bytes([int(rng.choice([0x00, 0x7F, 0xFF, 0x40, 0x80]))]) * int(rng.integers(1, 4000))
+        else:
+            out += rec(0, 5, 6, clk, rss)[: int(rng.integers(1, 11))]          # a record cut short, then more data
+    return bytes(out[:want])
+
+
+@pytest.mark.parametrize("as_text", [False, True])
+def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text):
+    """Random streams from a record grammar, as raw bytes and as capture text, in one batch per seed: counters, decoded
+    rows and kept rows against the oracle.  SLAMHIP_FUZZ_SEEDS widens the run (default 2 seeds of 150 streams)."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    n_seeds = int(os.environ.get("SLAMHIP_FUZZ_SEEDS", "2"))
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(9000 + seed + (500 if as_text else 0))
+        streams = [_grammar_stream(rng) for _ in range(150)]
+        payloads = streams
+        if as_text:
+            payloads = [("« " if rng.random() < 0.7 else "").encode("utf-8") + "".join(f"{b:02X} " for b in s).encode("ascii")
+                        for s in streams]
+        offs, lens, blob = [], [], bytearray()
+        for p in payloads:
+            while len(blob) % 16:
+                blob.append(0x20)
+            offs.append(len(blob)); lens.append(len(p)); blob += p
+        blob += b"\x20" * 64
+        text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+        pipe = FramePipeline(len(streams), max(max(lens), 1), tile_w=32, tile_h=32, mapping=mapping, lut=lut,
+                             src_is_bytes=not as_text)
+        pipe.set_layout(offs, lens)
+        pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+        st = pipe.stats_host()
+        for f, sbytes in enumerate(streams):
+            assert int(st[f, 1]) == 0, (seed, f)
+            rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+            assert (int(st[f, 2]), int(st[f, 3])) == (v, d), (seed, f, len(sbytes))
+            rows = pipe.frame_rows(f, st)
+            for k in rows_o:
+                assert np.array_equal(rows[k], rows_o[k]), (seed, f, k)
+            if v:
+                kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+                assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), (seed, f)
+                kept = pipe.frame_kept(f, st)
+                for k in kept_o:
+                    assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (seed, f, k)
+        del pipe, text
