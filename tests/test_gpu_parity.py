@@ -962,3 +962,62 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
                 for k in kept_o:
                     assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (seed, f, k)
         del pipe, text
+
+
+def test_render_stages_fuzz(ops, lut):
+    """Random tables through pivot, blur and colouring by the host-pointer entry points against the oracle: sparse
+    mappings with repeated angles and holes, a handful of rows up to thousands, beams outside 0..63, every blur width
+    from none to wider than the grid, linear and log scales with and without limits, tiles of odd sizes."""
+    from slamhip._lib import SlamError, E_ALLNAN, E_LIMITS
+    rng = np.random.default_rng(606)
+    n_cases = int(os.environ.get("SLAMHIP_FUZZ_CASES", "60"))
+    outcomes = {"ok": 0, "empty": 0, "limits": 0}
+    for case in range(n_cases):
+        beams = rng.choice(64, int(rng.integers(1, 65)), replace=False)
+        step = float(rng.choice([0.5, 1.0, 1.4, 3.0]))
+        mp = {int(b): float(np.round((int(b) // int(rng.integers(1, 4))) * step - 20.0, 3)) for b in beams}
+        n = int(rng.choice([1, 2, 7, 60, 900, 6000]))
+        lo_b, hi_b = (0, 64) if rng.random() < 0.8 else (-3, 70)
+        ue, bs = rng.integers(lo_b, hi_b, n), rng.integers(lo_b, hi_b, n)
+        if rng.random() < 0.3:                       # a narrow sweep: few cells, long empty stretches
+            ue, bs = ue % 5 + 10, bs % 3 + 40
+        rss = rng.integers(15000, 93000, n)
+        b2a, angles = ops.axis_from_mapping(mp)
+        s, c, m = ops.pivot_mean(ue, bs, rss, b2a, len(angles))
+        mat, aod, aoa, so, co = O.pivot_mean(ue, bs, rss, mp)
+        assert np.array_equal(s, so) and np.array_equal(c, co), case
+        if mat.size == 0:                            # no row with both beams mapped
+            outcomes["empty"] += 1
+            continue
+        rows, cols = np.flatnonzero(c.sum(1) > 0), np.flatnonzero(c.sum(0) > 0)
+        assert np.array_equal(m[np.ix_(rows, cols)], mat, equal_nan=True), case
+        sigma = float(rng.choice([0.0, 0.4, 1.0, 2.3, 7.0]))
+        bl, ob = ops.blur_nan(mat, sigma), O.blur_nan_aware(mat, sigma)
+        fin = np.isfinite(ob)
+        assert np.array_equal(np.isfinite(bl), fin), case
+        assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL, case
+        use_log = bool(rng.random() < 0.5)
+        given = rng.random() < 0.4
+        span = float(np.nanmax(bl) - np.nanmin(bl))
+        vmin = float(rng.uniform(-0.2, 0.6) * span + (0.0 if use_log else np.nanmin(bl))) if given else None
+        vmax = float(rng.uniform(0.5, 1.3) * span + (0.0 if use_log else np.nanmin(bl))) if given else None
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        try:
+            r = O.render(bl, aod, aoa, lut, use_log=use_log, vmin=vmin, vmax=vmax, blur_sigma=0.0, W=W, H=H)
+        except ValueError as ex:
+            with pytest.raises(SlamError) as ei:
+                ops.render(bl, aod, aoa, lut, use_log=use_log, vmin=vmin, vmax=vmax, W=W, H=H)
+            assert ei.value.code == (E_LIMITS if "vmin" in str(ex) else E_ALLNAN), (case, str(ex))
+            outcomes["limits"] += 1
+            continue
+        cells, tile, lo, hi = ops.render(bl, aod, aoa, lut, use_log=use_log, vmin=vmin, vmax=vmax, W=W, H=H)
+        assert (lo, hi) == (r["vmin"], r["vmax"]), case
+        d = np.abs(cells.astype(int) - r["cells"].astype(int)).max(axis=-1)
+        if use_log:
+            assert (d > 0).mean() <= 0.02 and d.max() <= 12, case
+            colmap, rowmap = O.raster_index_maps(O.edges(aoa), O.edges(aod), W, H)
+            assert np.array_equal(tile, cells[rowmap[:, None], colmap[None, :]]), case
+        else:
+            assert d.max() == 0 and np.array_equal(tile, r["tile"]), case
+        outcomes["ok"] += 1
+    assert outcomes["ok"] >= n_cases // 2, outcomes
