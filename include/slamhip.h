@@ -34,9 +34,9 @@ extern "C" {
 #define SLAM_E_CAPACITY     -3   /* an output buffer is too small; required size is reported */
 #define SLAM_E_EMPTY        -4   /* the stage produced no rows (the reference raises ValueError) */
 #define SLAM_E_ALLNAN       -5   /* matrix has no finite cell (excel_heatmap_v3.py:405-406) */
+#define SLAM_E_RANGE        -6   /* a value does not fit the device representation */
 #define SLAM_E_LIMITS       -7   /* log scale with a limit at or below the data minimum: the reference's LogNorm
                                     (excel_heatmap_v3.py:413-418) fails with "Invalid vmin or vmax" */
-#define SLAM_E_RANGE        -6   /* a value does not fit the device representation */
 
 typedef struct slam_ctx slam_ctx;
 
