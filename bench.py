@@ -67,8 +67,10 @@ def cpu_baseline(B, N, n_frames, tile):
     per = max(1, n_frames // cores)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     worker = os.path.join(ROOT, "oracle", "bench_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(B), str(N), str(w * per), str(per), str(tile)],
-                              stdout=subprocess.PIPE, env=env, text=True) for w in range(cores)]
+    import tempfile
+    dump = os.path.join(tempfile.mkdtemp(prefix="slam_bench_"), "frame0.npz")     # worker 0 leaves frame 0's results here
+    procs = [subprocess.Popen([sys.executable, worker, str(B), str(N), str(w * per), str(per), str(tile)] +
+                              ([dump] if w == 0 else []), stdout=subprocess.PIPE, env=env, text=True) for w in range(cores)]
     res = []
     for p in procs:
         out, _ = p.communicate(timeout=600)
@@ -85,11 +87,37 @@ def cpu_baseline(B, N, n_frames, tile):
         ref_offline = dict(frames_per_second_one_thread=round(rj["implied_frames_per_second_one_thread"], 5),
                            seconds_per_frame=round(rj["implied_seconds_per_256x4096_frame"], 1), where=rj["what"])
     return dict(value=total / slowest, unit="frames/s", cores=cores, kind="port", single_core_value=round(single, 3),
-                reference_offline=ref_offline,
+                reference_offline=ref_offline, _dump=dump,
                 sample=f"{total} synthetic {B}x{N} frames through oracle/ (sequential C scan + brute-force baseline "
                        f"search + NumPy blur/raster), {per} per worker process, {cores} single-threaded workers on "
                        f"{cores} of {os.cpu_count()} visible host cores, slowest worker {slowest:.1f} s "
                        f"({sum(r['dt'] for r in res):.0f} core-seconds)")
+
+
+def parity_check(pipe, text, dump):
+    """The device's results for synthetic frame 0 against what the CPU-baseline worker computed for the same frame
+    (the checker's side of the cpu_baseline leg): counters, decoded rows, kept rows and the mean matrix must be equal,
+    the blurred matrix within 1e-12, the tile's pixels equal.  One extra batch after the clock."""
+    z = np.load(dump)
+    pipe.run(text, text_base_offset=0)                  # batch 0 holds frames 0 .. F-1 of this rank
+    st = pipe.stats_host()
+    rows, kept = pipe.frame_rows(0, st), pipe.frame_kept(0, st)
+    full, bl, _aod, _aoa, lo, hi = pipe.frame_matrix(0, st)
+    rr, cc = np.flatnonzero(np.isfinite(full).any(axis=1)), np.flatnonzero(np.isfinite(full).any(axis=0))
+    fin = np.isfinite(z["blurred"])
+    blur_err = float(np.max(np.abs(bl[fin] - z["blurred"][fin]) / np.abs(z["blurred"][fin]))) if np.array_equal(np.isfinite(bl), fin) else float("inf")
+    out = dict(
+        frame=int(z["frame"]),
+        counters_equal=[int(st[0, k]) for k in (2, 3, 4, 5, 6)] == z["counters"].tolist(),
+        decoded_rows_equal=bool(np.array_equal(np.stack([rows[k].astype(np.int64) for k in ("flag", "ue", "bs", "rss", "clk")], 1), z["rows"])),
+        kept_rows_equal=bool(np.array_equal(np.stack([kept[k].astype(np.int64) for k in ("ue", "bs", "rss", "clk")], 1), z["kept"])),
+        matrix_equal=bool(np.array_equal(full[np.ix_(rr, cc)], z["matrix"], equal_nan=True)),
+        blurred_max_rel_err=blur_err,
+        tile_pixels_differing=int((pipe.frame_tile(0) != z["tile"]).any(axis=-1).sum()),
+    )
+    out["ok"] = bool(out["counters_equal"] and out["decoded_rows_equal"] and out["kept_rows_equal"] and out["matrix_equal"]
+                     and blur_err <= 1e-12 and out["tile_pixels_differing"] == 0)
+    return out
 
 
 def measured_ceilings(ctx, pipe, achieved_gbs):
@@ -307,6 +335,12 @@ def main():
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                     alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
 
+    if cpu_line is not None:
+        dump = cpu_line.pop("_dump")
+        if os.path.exists(dump):
+            cpu_line["parity_check"] = parity_check(pipe, text, dump)
+            os.remove(dump)
+            os.rmdir(os.path.dirname(dump))
     if roof is not None and rank == 0:
         roof["measured_ceilings"] = measured_ceilings(ctx, pipe, ach)
 
