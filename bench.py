@@ -16,7 +16,9 @@ Rank 0 prints ONE JSON line.  `value` is frames/s over all ranks with the text a
 the clock starts.  `roofline` prices the dominant kernel (algorithmic bytes / its mean duration from
 HIP events on the launch stream) against the 8 TB/s HBM peak; `cpu_baseline` is the CPU oracle
 (oracle/, a sequential C + NumPy restatement of the reference) timed here on a bounded sample, one
-single-threaded worker process per host core of the box's share (16).
+single-threaded worker process per host core of the box's share (16).  Two checks ride along after the clock:
+`cpu_baseline.parity_check` holds the device's results for frame 0 against that oracle's for the same frame, and
+`roofline.measured_ceilings` gives what plain read, copy and 3:1 read/write streams reach on the same device.
 """
 from __future__ import annotations
 
