@@ -541,6 +541,20 @@ def test_plain_c_host_of_the_abi(tmp_path):
     assert r.returncode == 2
 
 
+def test_plain_c_tour_of_every_host_entry_point():
+    """examples/cabi_tour.c: each host-pointer entry point called once from C on inputs whose results follow from the
+    reference's rules by hand (tokens, discards, a baseline and its corrections, pivot cells, blur, colours, tile
+    orientation, every error code); the program checks them itself."""
+    import subprocess
+    import __graft_entry__ as G
+    from conftest import ROOT
+    tour = os.path.join(ROOT, "examples", "cabi_tour")
+    if not os.path.exists(tour):
+        G.build()
+    r = subprocess.run([tour], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("tour ok"), (r.stdout, r.stderr)
+
+
 def test_complete_capture_end_to_end():
     """A complete capture of the reference (622 KB of text, 835 discarded groups, 8 sweeps) through the batched path:
     counters and kept rows as the reference's functions gave them, the mean matrix and the blurred matrix of its
