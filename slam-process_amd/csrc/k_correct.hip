@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
 #pragma unroll
                         for (int i = 0; i < 7; i++) pv[i] = (uint32_t)__builtin_amdgcn_readlane((int)t_r, 8 * i + 7);
                         in_reg_group = gg;
+                        in_lds_group = 0xFFFFFFFFu;       // pv no longer belongs to the table staged in LDS
                     }
                     // lower bound of every row's phase: the first three levels compare against seven entries held
                     // in scalar registers, the last four fetch one entry per row and step
@@ -1107,9 +1108,24 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                         }
                         __syncthreads();
                         in_lds_group = gg;
+                        // the seven entries the first three levels of every search compare against, kept in scalar
+                        // registers (P >= 128 here); the register table's copies are gone with them
+                        const uint32_t e8 = P >> 3;
+#pragma unroll
+                        for (int i = 0; i < 7; i++) pv[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_rb[e8 * (i + 1) - 1]);
+                        in_reg_group = 0xFFFFFFFFu;
                     }
-                    uint32_t lo[4] = {0, 0, 0, 0};
-                    for (uint32_t h = P >> 1; h; h >>= 1) {
+                    uint32_t lo[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r = r1[k];
+                        const bool a = pv[3] < r;
+                        const uint32_t m = a ? pv[5] : pv[1];
+                        const bool b = m < r;
+                        const uint32_t q = a ? (b ? pv[6] : pv[4]) : (b ? pv[2] : pv[0]);
+                        lo[k] = (a ? P >> 1 : 0u) + (b ? P >> 2 : 0u) + (q < r ? P >> 3 : 0u);
+                    }
+                    for (uint32_t h = P >> 4; h; h >>= 1) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
                     }
