@@ -1129,11 +1129,30 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
 #pragma unroll
                         for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
                     }
+                    if (prm.small_tol) {
+                        // as in the register path: with 0 <= 2*tol < cycle the forward distance to the successor and
+                        // the backward distance to the predecessor are the residuals; only the winner's payload is read
+                        const uint32_t cyc = (uint32_t)prm.cycle;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (fl[k] == 1 || gi[k] != gg) continue;
-                        int32_t bsn;
-                        if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                        for (int k = 0; k < 4; k++) {
+                            if (fl[k] == 1 || gi[k] != gg) continue;
+                            const bool wrap_s = lo[k] >= nd, wrap_p = lo[k] == 0;
+                            const uint32_t is = wrap_s ? 0u : lo[k], ip = wrap_p ? nd - 1u : lo[k] - 1u;
+                            const uint32_t rs_ = t_rb[is] + (wrap_s ? cyc : 0u) - r1[k], rp_ = r1[k] + (wrap_p ? cyc : 0u) - t_rb[ip];
+                            const bool pred = rp_ < rs_ || (rp_ == rs_ && t_pay[ip].x < t_pay[is].x);   // ties: the earlier baseline
+                            if ((pred ? rp_ : rs_) > (uint32_t)prm.tol) continue;
+                            const uint4 w = t_pay[pred ? ip : is];
+                            const uint32_t adj = pred ? (wrap_p ? 0xFFFFFFFFu : 0u) : (wrap_s ? 1u : 0u);
+                            res[k] = (int32_t)((w.z + (q1[k] - w.y) + adj) & (uint32_t)(prm.mod_base - 1));
+                            keep |= 1u << k;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (fl[k] == 1 || gi[k] != gg) continue;
+                            int32_t bsn;
+                            if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
+                        }
                     }
                 } else {
 #pragma unroll
