@@ -413,6 +413,37 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Bitonic sort of 64 * E dword keys held E per lane (element i = lane + 64 e sits in kv[e] of lane i % 64): stages
+// whose partner is less than 64 elements away exchange across lanes, the others compare registers of one lane.
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(uint32_t (&kv)[4], uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t k = 2; k <= 64u * E; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const uint32_t je = j >> 6;
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; e++) {
+                    if (e & je) continue;
+                    const uint32_t a = kv[e], b = kv[e | je], lo = min(a, b), hi = max(a, b);
+                    const bool asc = ((64u * e) & k) == 0;
+                    kv[e] = asc ? lo : hi;
+                    kv[e | je] = asc ? hi : lo;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < (uint32_t)E; e++) {
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ j) << 2), (int)kv[e]);
+                    const bool take_min = (((lane + 64u * e) & k) == 0) == ((lane & j) == 0);
+                    kv[e] = take_min ? min(kv[e], other) : max(kv[e], other);
+                }
+            }
+        }
+    }
+}
+
 // Groups with at most 64 baselines, one wave per group: bitonic sort of (phase, index) across the lanes with lane
 // exchanges, no LDS and no barriers.  Groups of 65 .. 256 baselines: still one wave per group, the network runs
 // over the wave's own piece of LDS (two or four elements per lane and stage), again without block barriers.
@@ -442,13 +473,36 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
             const uint32_t P = m <= 128 ? 128u : 256u;
             uint32_t T0 = 0, T1 = 0;
             if (bits.pay) { T0 = ws.grp_row[gs + g] / SLOT_ROWS; T1 = (ws.grp_row[gs + g + 1] - 1) / SLOT_ROWS; }
-            for (uint32_t i = lane; i < P; i += 64) {
+            // which tile's list holds baseline b0 + lane + 64 e: with the tiles' bases in one register per lane the
+            // owner is found by lane broadcasts, as below, instead of a chain of dependent loads per baseline
+            const bool by_lanes = bits.pay && T1 - T0 < 64;
+            uint32_t own[4] = {0, 0, 0, 0}, obase[4] = {0, 0, 0, 0};
+            uint32_t kv[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};      // dword keys (phase << 8 | index)
+            if (by_lanes) {
+                const uint32_t ntile = T1 - T0 + 1;
+                const uint32_t mine = lane < ntile ? bits.nbase[(size_t)f * bits.stride + T0 + lane] : 0xFFFFFFFFu;
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)mine, 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) obase[e] = first;
+                for (uint32_t t = 1; t < ntile; t++) {
+                    const uint32_t bt = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)t);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (bt <= b0 + lane + 64u * e) { own[e] = t; obase[e] = bt; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t i = lane + 64u * e;
+                if (i >= P) break;
                 unsigned long long key = ~0ull;
                 if (i < m) {
                     int32_t clk;
                     uint32_t bsv, q, r;
                     if (bits.pay) {
-                        const unsigned long long p = baseline_from_tiles(bits, f, b0 + i, T0, T1);
+                        const unsigned long long p = by_lanes
+                            ? bits.pay[((size_t)f * bits.stride + T0 + own[e]) * BL_PAY_CAP + (b0 + i - obase[e])]
+                            : baseline_from_tiles(bits, f, b0 + i, T0, T1);
                         clk = (int32_t)(uint32_t)p;
                         bsv = (uint32_t)((p >> 32) & 0xFFu);
                     } else {
@@ -459,10 +513,37 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
                     key = ((unsigned long long)r << 32) | i;
                     sq[i] = q;
                     sb[i] = bsv;
+                    kv[e] = (r << 8) | i;
                 }
                 kk[i] = key;
             }
             wave_lds_fence();
+            if ((uint32_t)prm.cycle < (1u << 24)) {
+                // phase and index fit one dword: the whole network runs in registers and lane exchanges
+                if (P == 128) wave_sort_regs<2>(kv, lane); else wave_sort_regs<4>(kv, lane);
+                uint32_t run = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t i = lane + 64u * e;
+                    if (64u * e >= P) break;
+                    // the element before: the lane to the left, or lane 63 of the register before for lane 0
+                    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)kv[e > 0 ? e - 1 : 0], 63);
+                    uint32_t left = (uint32_t)__shfl_up((int)kv[e], 1, 64);
+                    if (lane == 0) left = before;
+                    const bool keep = i < m && (i == 0 || (left >> 8) != (kv[e] >> 8));
+                    const uint64_t km = __ballot(keep);
+                    if (keep) {
+                        const uint32_t o = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                        const uint32_t idx = kv[e] & 255u;
+                        ws.srt_rb[bsb + b0 + o] = kv[e] >> 8;
+                        ws.srt_pay[bsb + b0 + o] = make_uint4(idx, sq[idx], sb[idx], 0);
+                    }
+                    run += (uint32_t)__popcll(km);
+                }
+                if (lane == 0) ws.grp_nd[gs + g] = run;
+                wave_lds_fence();
+                continue;
+            }
             for (uint32_t k = 2; k <= P; k <<= 1) {
                 for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                     for (uint32_t p = lane; p < P / 2; p += 64) {         // pair p: element i and its partner i | j

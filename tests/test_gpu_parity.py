@@ -179,10 +179,11 @@ def test_correct_large_group_rank_path(ops):
         assert np.array_equal(a.astype(np.int64), kept_o[k]), k
 
 
-@pytest.mark.parametrize("cyc", [61000, 97])
+@pytest.mark.parametrize("cyc", [61000, 97, (1 << 24) + 43, (1 << 27) + 5])
 def test_correct_mid_sized_groups(ops, cyc):
-    """Groups of 65 .. 256 baselines on the int32 entry point (one wave sorts each in LDS); the short cycle makes most
-    phases repeat, so the earliest-baseline rule decides."""
+    """Groups of 65 .. 256 baselines on the int32 entry point (one wave sorts each: dword keys in registers, or
+    64-bit keys in LDS for cycles of 2^24 and more); the short cycle makes most phases repeat, so the
+    earliest-baseline rule decides."""
     rng = np.random.default_rng(cyc)
     cols = []
     for m in (65, 66, 127, 128, 129, 200, 255, 256, 257, 64):
