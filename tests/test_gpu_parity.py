@@ -1056,3 +1056,26 @@ def test_batched_results_do_not_depend_on_scheduling(mapping, lut):
     rev = snapshot(list(range(F))[::-1])
     assert rev[::-1] == first
     assert len({p[5] for p in first}) == F                      # and the frames do differ from one another
+
+
+@pytest.mark.parametrize("n_baselines", [40, 100, 250])
+def test_batched_correction_long_groups_with_few_baselines(mapping, lut, n_baselines):
+    """Groups whose rows span more than 64 tiles (20 000 rows each) with a few dozen to a few hundred baselines: the
+    sorts then find each baseline's tile by a search over the tile bases instead of lane broadcasts."""
+    import torch
+    from slamhip import _lib
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    sbytes = _wrap_stream(61000, 31, groups=2, rows_per_group=20000, n_baselines=n_baselines)
+    assert len(sbytes) // 2 > 64 * _lib.TILE_BYTES
+    text = torch.from_numpy(np.frombuffer(sbytes + b"\xEE" * 64, np.uint8).copy()).cuda()
+    pipe = FramePipeline(1, len(sbytes), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True)
+    pipe.set_layout([0], [len(sbytes)])
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+    kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+    assert ng == 2 and nb >= 2 * n_baselines - 4 and len(kept_o["ue"]) > 1000
+    assert (int(st[0, 2]), int(st[0, 4]), int(st[0, 5]), int(st[0, 6])) == (v, ng, nb, len(kept_o["ue"]))
+    kept = pipe.frame_kept(0, st)
+    for k in kept_o:
+        assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
