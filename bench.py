@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one batch of F synthetic 256 x 4096 frames (BASELINE.json configs[1]) through
+One step = one batch of F synthetic 256 x 4096 frames (the shape the headline metric is quoted on) through
 slam_process_frames_dev: hex text resident in HBM -> decoded records -> corrected rows -> mean matrix ->
 blur -> 1024 x 1024 RGBA tile per frame.  With N > 1 (launched by torch.distributed.run, one rank per
 GPU) every rank processes its own frames (weak scaling) and every step's results are gathered to rank 0

@@ -118,7 +118,7 @@ def test_errors_follow_the_reference(tmp_path):
 
 
 def test_full_size_frames_bit_exact():
-    """BASELINE.json's 256 x 4096 shape, two frames, every integer output against the oracle."""
+    """The benchmark's 256 x 4096 shape, two frames, every integer output against the oracle."""
     import torch
     from slamhip import synth
     from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
@@ -185,7 +185,7 @@ def test_ragged_batch_of_captures_with_loose_text():
 
 @pytest.mark.parametrize("shape", [(256, 16384), (1024, 8192)])
 def test_long_sweep_and_wide_frames_bit_exact(shape):
-    """BASELINE.json's other synthetic shapes (256 x 16384 long sweeps, 1024 x 8192) against the oracle."""
+    """The other two synthetic shapes the benchmark is specified for (256 x 16384 long sweeps, 1024 x 8192) against the oracle."""
     from slamhip import synth
     from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
     B, N = shape
@@ -657,7 +657,7 @@ def test_every_capture_of_the_reference_as_one_ragged_batch():
 
 
 def test_batch_driver_every_capture_over_four_ranks(tmp_path):
-    """BASELINE's third configuration in small: all 19 capture logs of the reference under their own file names, the
+    """The every-capture configuration in small: all 19 capture logs of the reference under their own file names, the
     driver under torch.distributed with four ranks (sharing this GPU, gloo collectives through the host).  Files are
     balanced over the ranks by size, every log's summary line carries the reference's counters, and rank 0 writes
     every tile: the bytes the single-process batch renders."""
