@@ -73,7 +73,8 @@ def test_reference_functions_on_full_captures(ref):
             assert np.array_equal(rows[k].astype(np.int64), arr[:, j])
 
 
-def test_reference_functions_on_a_synthetic_frame(ref, tmp_path):
+@pytest.mark.parametrize("shape", [(8, 1024, 3), (3, 4096, 0)])
+def test_reference_functions_on_a_synthetic_frame(ref, tmp_path, shape):
     """The benchmark's kind of data (slamhip/synth.py, 8 sweeps of 1024 records) through the reference's own
     _read_bytes, _parse_groups and the group loop of process_excel_filtered, against the oracle: the frames the
     throughput is measured on are covered by the same pin as the captures."""
@@ -85,7 +86,8 @@ def test_reference_functions_on_a_synthetic_frame(ref, tmp_path):
     B = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(B)
     lg = logging.getLogger("pin")
-    text = synth.make_frame_text(8, 1024, 3).tobytes()
+    B_rows, N_rec, frame_id = shape        # the second shape has the benchmark's sweep length: 63 baselines per group
+    text = synth.make_frame_text(B_rows, N_rec, frame_id).tobytes()
     p = tmp_path / "f.txt"
     p.write_bytes(text)
     by_ref = ref._read_bytes(Path(p), lg)
@@ -105,7 +107,7 @@ def test_reference_functions_on_a_synthetic_frame(ref, tmp_path):
             pieces.append(f)
     res = pd.concat(pieces, ignore_index=True).to_numpy().astype(np.int64)
     kept, ng, nb = O.filter_corrected(*arr.T)
-    assert ng == int(df["_gid"].max()) + 1 == 8
+    assert ng == int(df["_gid"].max()) + 1 == B_rows and nb >= 15 * B_rows * (N_rec // 1024)
     assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), res)
 
 
