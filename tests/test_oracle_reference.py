@@ -73,7 +73,7 @@ def test_reference_functions_on_full_captures(ref):
             assert np.array_equal(rows[k].astype(np.int64), arr[:, j])
 
 
-@pytest.mark.parametrize("shape", [(8, 1024, 3), (3, 4096, 0)])
+@pytest.mark.parametrize("shape", [(8, 1024, 3), (3, 4096, 0), (1, 16384, 5)])
 def test_reference_functions_on_a_synthetic_frame(ref, tmp_path, shape):
     """The benchmark's kind of data (slamhip/synth.py, 8 sweeps of 1024 records) through the reference's own
     _read_bytes, _parse_groups and the group loop of process_excel_filtered, against the oracle: the frames the
