@@ -227,6 +227,21 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
  * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones). */
 int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
 
+/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference, which has no device memory to manage.  Where
+ * slam_process_frames_dev takes its scratch (per-tile bit masks and counts, baseline lists, group and phase tables,
+ * pivot accumulators, the blur weights) from the ctx workspace and grows that on demand, this entry point takes it from
+ * a fixed array of SLAM_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from the first slam_ctx_create
+ * on it until the process ends.  It calls no hipMalloc / hipFree and copies nothing from the host (the blur weights
+ * travel as a kernel argument); kernel timing is off for the call.  Same batch, same stages, same results.
+ * Limits: SLAM_E_CAPACITY when the batch shape needs more scratch than the array holds (one 256 x 4096-record frame
+ * needs about 54 MB; several smaller frames fit together), SLAM_E_RANGE for a blur of more than 21 taps
+ * (sigma > 3.5).  All calls on one GPU share that GPU's array, whatever their ctx or stream: two calls that overlap
+ * in time on one GPU race, and a call may not overlap slam_process_frames_dev output it still needs from the array
+ * (tile_cnt / kept_cnt / cells / colmap / rowmap left NULL live there until the next call). */
+#define SLAM_NOALLOC_SCRATCH_BYTES (64u << 20)
+int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
+
 /* Paint n_frames tiles from cell colours and pixel->cell maps as slam_process_frames_dev leaves them
  * (cells_dev / colmap_dev / rowmap_dev / stats_dev of slam_batch, same strides): the last step of
  * generate_heatmap's mesh (excel_heatmap_v3.py:442-446) on its own.  Device pointers, asynchronous. */

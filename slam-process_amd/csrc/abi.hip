@@ -8,6 +8,33 @@
 #include "pipeline.hpp"
 
 // ------------------------------------------------------------------------------------------------------
+// fixed device scratch of the allocation-free entry point (slam_process_frames_noalloc_dev)
+// ------------------------------------------------------------------------------------------------------
+// Every GPU the library runs on holds its own copy of this array, at its own address, until the process ends.
+// `scratch` itself is only the host-side handle of the symbol: host code never passes it to a kernel or to a
+// memory routine.  The device address is looked up once per device (resolve_scratch, from slam_ctx_create with that
+// device current) and kept in scratch_ptr[device]; kernels receive that pointer as an argument, exactly as they
+// receive the ctx workspace in slam_process_frames_dev.
+static __device__ __align__(256) unsigned char scratch[SLAM_NOALLOC_SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static unsigned char *scratch_ptr[SCRATCH_MAX_DEVICES];
+constexpr int NOALLOC_KMAX = 21;                          // blur taps per side the by-value kernel upload can carry
+constexpr size_t NOALLOC_KERN_BYTES = 4096;               // front of the scratch: the Gaussian weights (21 * 21 doubles)
+static_assert(NOALLOC_KMAX * NOALLOC_KMAX * sizeof(double) <= NOALLOC_KERN_BYTES, "kernel weights fit their piece");
+
+static hipError_t resolve_scratch(int device)              // `device` must be the current device
+{
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (scratch_ptr[device]) return hipSuccess;
+    unsigned char *p = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    scratch_ptr[device] = p;
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------
 int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...)
@@ -30,6 +57,8 @@ extern "C" int slam_ctx_create(int device, slam_ctx **out)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SLAM_E_HIP;
     if (hipSetDevice(device) != hipSuccess) return SLAM_E_HIP;
+    // this device's copy of the fixed scratch array (devices beyond the table simply have no allocation-free path)
+    if (device < SCRATCH_MAX_DEVICES && resolve_scratch(device) != hipSuccess) return SLAM_E_HIP;
     slam_ctx *c = new slam_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SLAM_E_HIP; }
@@ -746,13 +775,9 @@ extern "C" int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch)
     return slam_ws_reserve(ctx, bp.total);
 }
 
-extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
+// argument checks shared by the two batched entry points
+static int check_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
 {
-    REQUIRE_CTX(ctx);
-    batch_plan bp;
-    SLAM_TRY(plan_batch(ctx, bt, bp));
-    const uint32_t F = bt->n_frames;
-    if (F == 0) return SLAM_OK;
     if ((stages & 1u) && (!bt->flag_dev || !bt->ue_dev || !bt->bs_dev || !bt->rss_dev || !bt->clk_dev))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays are required");
     if ((stages & 2u) && (!bt->kept_ue_dev || !bt->kept_bs_dev || !bt->kept_rss_dev || !bt->kept_clk_dev))
@@ -760,8 +785,20 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if ((stages & 4u) && (!bt->beam_to_axis_dev || !bt->axis_angle_dev || !bt->lut_dev || bt->n_axis < 1 ||
                           bt->n_axis > 64 || (bt->tile_dev && (bt->tile_w < 1 || bt->tile_h < 1))))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: render stage needs the axis table, LUT and tile size");
-    SLAM_TRY(slam_ws_reserve(ctx, bp.total));
-    uint8_t *b = ctx->ws;
+    if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
+         (uintptr_t)bt->clk_dev) & 15u)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays must be 16-byte aligned");
+    if ((stages & 2u) && (bt->cycle <= 0 || bt->cycle > (1 << 30)))
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");
+    return SLAM_OK;
+}
+
+// One batch with its scratch at `b` (bp.total bytes, laid out by plan_batch) and the ks x ks blur weights at `kern`:
+// only kernel launches on the ctx's stream from here on.
+static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const batch_plan &bp, uint8_t *b,
+                     const double *kern, int ks)
+{
+    const uint32_t F = bt->n_frames;
     frame_ws fws;
     fws.bind(b, bp.fw, bp.nt_max);
     correct_ws cws;
@@ -780,9 +817,6 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     tbits.pay = (unsigned long long *)(b + bp.tb[2]);
     tbits.stride = bp.st_max;
     if (stages & 2u) rows.bits = tbits;          // the framing pass leaves the correction's per-tile bits
-    if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
-         (uintptr_t)bt->clk_dev) & 15u)
-        return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: decoded-record arrays must be 16-byte aligned");
     const uint32_t kept_stride = (bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : cws.rt_nkept;
     if (stages & 1u) {
@@ -798,7 +832,6 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
         in.bits_fresh = (stages & 1u) ? 1 : 0;
         kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev,
                                           kept_cnt, kept_stride};
-        if (bt->cycle <= 0 || bt->cycle > (1 << 30)) return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: cycle must be in 1..2^30");
         correct_params prm;
         prm.set_cycle(bt->cycle);
         prm.tol = bt->tol;
@@ -808,9 +841,6 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
     if (stages & 4u) {
         render_params rp{bt->beam_to_axis_dev, bt->axis_angle_dev, bt->n_axis, bt->blur_sigma, bt->use_log,
                          bt->vmin, bt->vmax, bt->lut_dev, bt->tile_w, bt->tile_h};
-        double *kern;
-        int ks;
-        SLAM_TRY(get_kernel(ctx, bt->blur_sigma, &kern, &ks));
         SLAM_TRY((pivot_accumulate<uint8_t, uint32_t>(ctx, bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev,
                                                       bt->row_cap, F, bt->stats_dev, SLAM_STAT_ROW_SLOTS, rp, rws,
                                                       kept_cnt, kept_stride)));
@@ -818,4 +848,85 @@ extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint
                                     bt->stats_dev));
     }
     return SLAM_OK;
+}
+
+extern "C" int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
+{
+    REQUIRE_CTX(ctx);
+    batch_plan bp;
+    SLAM_TRY(plan_batch(ctx, bt, bp));
+    if (bt->n_frames == 0) return SLAM_OK;
+    SLAM_TRY(check_batch(ctx, bt, stages));
+    SLAM_TRY(slam_ws_reserve(ctx, bp.total));
+    double *kern = nullptr;
+    int ks = 1;
+    if (stages & 4u) SLAM_TRY(get_kernel(ctx, bt->blur_sigma, &kern, &ks));
+    return run_batch(ctx, bt, stages, bp, ctx->ws, kern, ks);
+}
+
+// ---- the same call on the library's fixed device scratch: nothing is allocated ---------------------------
+namespace {
+struct kern_by_value { double w[NOALLOC_KMAX * NOALLOC_KMAX]; };
+// The Gaussian weights travel as a launch argument (3.5 KB) and are written to the scratch by the kernel itself:
+// no host-to-device copy, so the step is an ordinary kernel node for a caller capturing the stream.
+__global__ __launch_bounds__(256) void k_store_weights(kern_by_value k, int n, double *dst)
+{
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = k.w[i];
+}
+}  // namespace
+
+extern "C" int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
+{
+    REQUIRE_CTX(ctx);
+    batch_plan bp;
+    SLAM_TRY(plan_batch(ctx, bt, bp));
+    if (bt->n_frames == 0) return SLAM_OK;
+    SLAM_TRY(check_batch(ctx, bt, stages));
+    if (ctx->device >= SCRATCH_MAX_DEVICES || !scratch_ptr[ctx->device])
+        return slam_fail(ctx, SLAM_E_HIP, "slam_process_frames_noalloc_dev: no fixed scratch on device %d", ctx->device);
+    if (bp.total + NOALLOC_KERN_BYTES > (size_t)SLAM_NOALLOC_SCRATCH_BYTES)
+        return slam_fail(ctx, SLAM_E_CAPACITY,
+                         "slam_process_frames_noalloc_dev: this batch shape needs %zu bytes of scratch, the fixed array "
+                         "holds %zu (fewer or shorter frames per call, or slam_process_frames_dev)",
+                         bp.total + NOALLOC_KERN_BYTES, (size_t)SLAM_NOALLOC_SCRATCH_BYTES);
+    uint8_t *base = scratch_ptr[ctx->device];                 // the device address, never the symbol's name
+    double *kern = reinterpret_cast<double *>(base);
+    int ks = 1;
+    const bool timing = ctx->timing;                          // event timers create events: off for this call
+    ctx->timing = false;
+    int rc = SLAM_OK;
+    if (stages & 4u) {
+        const double sigma = bt->blur_sigma;
+        kern_by_value kv;
+        if (sigma != sigma) rc = slam_fail(ctx, SLAM_E_INVALID, "blur sigma is NaN");
+        else if (sigma > 0) {
+            // gaussian_kernel (excel_heatmap_v3.py:320-333) on the stack, same arithmetic as slam_gaussian_kernel_host
+            if (ceil(6.0 * sigma) > (double)NOALLOC_KMAX) {
+                rc = slam_fail(ctx, SLAM_E_RANGE, "slam_process_frames_noalloc_dev: blur sigma %.3f needs more than %d taps",
+                               sigma, NOALLOC_KMAX);
+            } else {
+                int size = (int)fmax(3.0, ceil(6.0 * sigma));
+                if (size % 2 == 0) size++;
+                const int c = size / 2;
+                double total = 0.0;
+                for (int y = -c; y <= c; y++)
+                    for (int x = -c; x <= c; x++) {
+                        const double v = exp(-(double)(x * x + y * y) / (2.0 * sigma * sigma));
+                        kv.w[(y + c) * size + (x + c)] = v;
+                        total += v;
+                    }
+                for (int i = 0; i < size * size; i++) kv.w[i] /= total;
+                ks = size;
+            }
+        } else {
+            kv.w[0] = 1.0;
+        }
+        if (rc == SLAM_OK) {
+            hipLaunchKernelGGL(k_store_weights, dim3(1), dim3(256), 0, ctx->stream, kv, ks * ks, kern);
+            if (hipGetLastError() != hipSuccess) rc = slam_fail(ctx, SLAM_E_HIP, "launch of store_weights failed");
+        }
+    }
+    if (rc == SLAM_OK) rc = run_batch(ctx, bt, stages, bp, base + NOALLOC_KERN_BYTES, kern, ks);
+    ctx->timing = timing;
+    return rc;
 }

@@ -21,11 +21,12 @@ STAT_WORDS = 16
  STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI,
  STAT_ROW_SLOTS, STAT_TWO_PASS) = range(16)
 TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
+NOALLOC_SCRATCH_BYTES = 64 << 20
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
-    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_batch_sizeof",
+    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
@@ -101,6 +102,7 @@ def load() -> C.CDLL:
         lib.slam_render.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, f64, f64, vp, vp, vp,
                                     C.c_int, C.c_int, vp]
         lib.slam_process_frames_dev.argtypes = [vp, C.POINTER(Batch), u32]
+        lib.slam_process_frames_noalloc_dev.argtypes = [vp, C.POINTER(Batch), u32]
         lib.slam_reserve_workspace.argtypes = [vp, C.POINTER(Batch)]
         lib.slam_batch_sizeof.restype = sz
         if lib.slam_batch_sizeof() != C.sizeof(Batch):

@@ -42,7 +42,7 @@ class FramePipeline:
                  blur_sigma: float = 1.0, use_log: bool = False, vmin: Optional[float] = None,
                  vmax: Optional[float] = None, cycle: int = ops.CYCLE, tol: int = ops.TOL,
                  mod_base: int = ops.MOD_BASE, src_is_bytes: bool = False, n_tile_slots: Optional[int] = None,
-                 n_compact_slots: int = 1):
+                 n_compact_slots: int = 1, reserve: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("FramePipeline needs a GPU (the HIP path has no CPU fallback)")
         self.dev = torch.device("cuda", device)
@@ -113,9 +113,11 @@ class FramePipeline:
         bt.text_len_dev = self.len.data_ptr()
         self.bt = bt
         self._text_keep = None
-        # reserve the library workspace once, so steady-state calls allocate nothing
+        # reserve the library workspace once, so steady-state calls allocate nothing (reserve=False: a pipeline that
+        # only ever runs on the library's fixed scratch, run(..., noalloc=True))
         bt.text_dev = self.flag.data_ptr()          # any non-null pointer: only the shape matters here
-        self.ctx.check(self.ctx.lib.slam_reserve_workspace(self.ctx.h, C.byref(bt)))
+        if reserve:
+            self.ctx.check(self.ctx.lib.slam_reserve_workspace(self.ctx.h, C.byref(bt)))
 
     def _point_compact(self, bt, slot: int) -> None:
         base, lay = self.compact[slot].data_ptr(), self.compact_layout
@@ -146,15 +148,17 @@ class FramePipeline:
         self.bt.n_frames = n
 
     def run(self, text: torch.Tensor, text_base_offset: int = 0, stages: int = STAGE_ALL, tile_slot: int = 0,
-            compact_slot: Optional[int] = None) -> None:
-        """Enqueue one batch on torch's current stream (no synchronisation)."""
+            compact_slot: Optional[int] = None, noalloc: bool = False) -> None:
+        """Enqueue one batch on torch's current stream (no synchronisation).  noalloc: through
+        slam_process_frames_noalloc_dev, on the library's fixed device scratch instead of the ctx workspace."""
         self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         if compact_slot is not None and compact_slot != self.compact_slot:
             self._point_compact(self.bt, int(compact_slot))
         self._text_keep = text
         self.bt.text_dev = text.data_ptr() + int(text_base_offset)
         self.bt.tile_dev = self.tiles.data_ptr() + int(tile_slot) * self.tile_h * self.tile_w * 4
-        self.ctx.check(self.ctx.lib.slam_process_frames_dev(self.ctx.h, C.byref(self.bt), int(stages)))
+        call = self.ctx.lib.slam_process_frames_noalloc_dev if noalloc else self.ctx.lib.slam_process_frames_dev
+        self.ctx.check(call(self.ctx.h, C.byref(self.bt), int(stages)))
 
     # ---- read-back helpers (synchronise) -----------------------------------------------------
     def stats_host(self) -> np.ndarray:
