@@ -117,7 +117,7 @@ int main(void)
                        NULL, NULL, NULL, NULL, &kept, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == SLAM_E_RANGE);
 
     /* ---- a9 - a10: pivot over three angles; beam 5 is unmapped, beams 0 and 1 share an angle */
-    int8_t b2a[64];
+    int16_t b2a[64];
     memset(b2a, -1, sizeof b2a);
     b2a[0] = 0; b2a[1] = 0; b2a[2] = 1; b2a[3] = 2;
     const int32_t pue[6] = {0, 1, 2, 3, 5, 70}, pbs[6] = {2, 2, 3, 0, 2, 2}, prs[6] = {10, 21, 7, 9, 1000, 1000};

@@ -115,11 +115,14 @@ int slam_correct(slam_ctx *ctx,
 /* ---- a9-a10: angle mapping + mean pivot ---------------------------------------------------------
  * Replaces map_angles (excel_heatmap_v3.py:264-280) + compute_rssi_matrix (:286-314).
  * beam_to_axis[64]: index of each beam's angle among the sorted distinct mapped angles, -1 if
- * unmapped (rows using it are dropped); n_axis <= 64.  Rows with a beam outside 0..63 are dropped.
+ * unmapped (rows using it are dropped); n_axis <= SLAM_MAX_AXIS.  The reference's table has 64 entries, so
+ * n_axis <= 64 there; a larger axis is the up-scaled table of slam_batch.full_grid, where beam b sits at entry
+ * 4 * b of a 256-entry table.  Rows with a beam outside 0..63 are dropped.
  * sum/cnt: exact integer accumulators [n_axis*n_axis] (row = AoD axis of BS, col = AoA axis of UE).
  * matrix: mean as f64, NaN where cnt == 0, same layout.  rss values must be in [0, 2^31). */
+#define SLAM_MAX_AXIS 256
 int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const int32_t *rss, size_t n,
-                    const int8_t *beam_to_axis, int n_axis,
+                    const int16_t *beam_to_axis, int n_axis,
                     int64_t *sum, int64_t *cnt, double *matrix);
 
 /* ---- a11-a12: NaN-aware Gaussian blur --------------------------------------------------------------
@@ -132,7 +135,7 @@ int slam_blur_nan(slam_ctx *ctx, const double *in, int h, int w, double sigma, d
  * Replaces the data path of generate_heatmap (:396-456) after the blur: finite min/max,
  * Normalize / shifted LogNorm, 256-entry colormap lookup, and the pcolormesh of flat cells with
  * edges at midpoints (_edges :430-440), sampled into a data-only W x H RGBA tile (row 0 = largest
- * AoD).  vmin/vmax (NaN = none given) count on the log scale only: the reference hands the linear mesh neither a
+ * AoD); h, w <= SLAM_MAX_AXIS.  vmin/vmax (NaN = none given) count on the log scale only: the reference hands the linear mesh neither a
  * norm nor limits (:420-423, :449-456), so its linear scale always spans the finite data.  Empty and reversed
  * intervals come out as matplotlib's colour bar leaves them (expanded by a tenth).  Outputs (any may be NULL):
  * cells_rgba [h*w*4], tile_rgba [H*W*4], vmin_vmax_out[2] the limits used (after the log shift when use_log). */
@@ -156,9 +159,14 @@ typedef struct slam_batch {
     uint32_t src_is_bytes;        /* 0: text_dev holds hex text in the capture format;            */
                                   /* 1: it holds already-unpacked data bytes (slam_hex_unpack)    */
     int32_t cycle, tol, mod_base; /* CYCLE, TOL, MOD_BASE (bs_beam_correction.py:23-25)          */
-    const int8_t *beam_to_axis_dev;   /* [64]                                                    */
+    const int16_t *beam_to_axis_dev;  /* [64] axis entry of each beam, -1 = unmapped             */
     const double *axis_angle_dev;     /* [n_axis] sorted distinct angles                         */
-    int32_t n_axis;
+    int32_t n_axis;                   /* 1 .. SLAM_MAX_AXIS                                      */
+    int32_t full_grid;                /* 0: rows / columns of the matrix are the angles that occur, as     */
+                                      /* compute_rssi_matrix (excel_heatmap_v3.py:301-307) builds them;    */
+                                      /* 1: every entry of the axis table is a row and a column (the       */
+                                      /* up-scaled table mode: no counterpart in the reference, whose      */
+                                      /* validate_beam_id :68-72 admits 64 beams)                          */
     double blur_sigma;            /* --blur-sigma, default 1.0 (excel_heatmap_v3.py:601-603)      */
     int32_t use_log;              /* --logscale                                                   */
     double vmin, vmax;            /* NaN = none given; used on the log scale only (see slam_render) */
@@ -187,10 +195,14 @@ typedef struct slam_batch {
     /* optional: what the tile is painted from (NULL: kept in the ctx workspace).  tile[py][px] =
      * cells[rowmap[py] * N_AOA + colmap[px]]; with the frame's stats words these 20 KB reproduce the tile
      * bit for bit through slam_raster_dev, e.g. on the rank that collects results. */
-    uint8_t *cells_dev;           /* [F*4096*4] RGBA per cell of the compact matrix               */
+    uint8_t *cells_dev;           /* [F*slam_cells_per_frame(n_axis)*4] RGBA per cell of the compact matrix */
     int16_t *colmap_dev;          /* [F*tile_w] pixel column -> cell column                       */
     int16_t *rowmap_dev;          /* [F*tile_h] pixel row -> cell row                             */
 } slam_batch;
+
+/* Cells reserved per frame in cells_dev and in slam_raster_dev: 4096 for axis tables of up to 64 entries,
+ * n_axis * n_axis beyond. */
+uint32_t slam_cells_per_frame(int32_t n_axis);
 
 /* sizeof(slam_batch) as the library was built with: a binding compares it with its own mirror of the struct
  * before the first call (no counterpart in the reference, which has no binary interface). */
@@ -204,7 +216,8 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 
 #define SLAM_STAT_WORDS      16
 #define SLAM_STAT_NBYTES      0   /* data bytes decoded from the text                            */
-#define SLAM_STAT_NOT_STRICT  1   /* 1 = text is not in the strict capture format: frame skipped  */
+#define SLAM_STAT_NOT_STRICT  1   /* 1 = text is not in the strict capture format: the frame comes back with no rows   */
+                                  /* (VALID, DISCARDED, ROW_SLOTS, GROUPS, BASELINES, KEPT all 0, ALLNAN 1, tile blank) */
 #define SLAM_STAT_VALID       2   /* reference's `valid`                                          */
 #define SLAM_STAT_DISCARDED   3   /* reference's `discarded`                                      */
 #define SLAM_STAT_GROUPS      4
@@ -246,11 +259,22 @@ int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *batch, uint
  * (cells_dev / colmap_dev / rowmap_dev / stats_dev of slam_batch, same strides): the last step of
  * generate_heatmap's mesh (excel_heatmap_v3.py:442-446) on its own.  Device pointers, asynchronous. */
 int slam_raster_dev(slam_ctx *ctx, const uint8_t *cells_dev, const int16_t *colmap_dev, const int16_t *rowmap_dev,
-                    const uint32_t *stats_dev, uint32_t n_frames, int32_t tile_w, int32_t tile_h, uint8_t *tile_dev);
+                    const uint32_t *stats_dev, uint32_t n_frames, int32_t tile_w, int32_t tile_h, uint8_t *tile_dev,
+                    uint32_t cells_per_frame /* slam_cells_per_frame(n_axis) of the producing batch */);
 
 /* Bytes of ctx workspace slam_process_frames_dev needs for this batch shape (it grows the
- * workspace itself on first use; callers that must not allocate later call this once up front). */
+ * workspace itself on first use; callers that must not allocate later call this once up front).  Also uploads the
+ * blur weights of batch->blur_sigma. */
 int slam_reserve_workspace(slam_ctx *ctx, const slam_batch *batch);
+
+/* Growing the workspace frees and reallocates it, and a blur sigma other than the reserved one re-uploads the
+ * weights: both would silently invalidate every HIP graph captured from calls on this ctx (the captured kernels hold
+ * workspace addresses).  While the ctx's stream is being captured such a call fails with SLAM_E_INVALID instead.
+ * slam_pin_workspace(ctx, 1) extends that protection past the capture: until unpinned, any call on the ctx (the
+ * host-pointer entry points included) that needs more workspace than is reserved fails with SLAM_E_CAPACITY rather
+ * than reallocate.  A caller that replays captured graphs pins the ctx after capturing, or keeps a ctx of its own per
+ * captured pipeline (slamhip.pipeline.FramePipeline does the latter).  No counterpart in the reference. */
+int slam_pin_workspace(slam_ctx *ctx, int pinned);
 
 /* Deterministic synthetic capture generator (device): frame `frame_index` of shape B rows x
  * N records into text_dev (needs slam_synth_text_len(B, N) bytes).  Byte-identical to the

@@ -356,7 +356,7 @@ void orc_correct_inplace(const int64_t *flag, const int64_t *ue, const int64_t *
  * AoA axis index of UE); the mean is sum/count in f64 (pivot_table mean).
  */
 void orc_pivot(const int64_t *ue, const int64_t *bs, const int64_t *rss, int64_t n,
-               const int8_t *beam_to_axis, int n_axis, int64_t *sum, int64_t *cnt)
+               const int16_t *beam_to_axis, int n_axis, int64_t *sum, int64_t *cnt)
 {
     memset(sum, 0, sizeof(int64_t) * (size_t)n_axis * (size_t)n_axis);
     memset(cnt, 0, sizeof(int64_t) * (size_t)n_axis * (size_t)n_axis);

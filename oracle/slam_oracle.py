@@ -302,23 +302,48 @@ def correct_table_nulls_py(rows, filtered: bool, cycle=CYCLE, tol=TOL, mod_base=
 # a8-a10  mapping table, map_angles, compute_rssi_matrix
 # ---------------------------------------------------------------------------
 def axis_from_mapping(mapping: Dict[int, float]) -> Tuple[np.ndarray, np.ndarray]:
-    """BeamID->angle dict (ids 0..63, excel_heatmap_v3.py:246-247) -> (beam_to_axis int8[64], sorted distinct angles)."""
+    """BeamID->angle dict (ids 0..63, excel_heatmap_v3.py:246-247) -> (beam_to_axis int16[64], sorted distinct angles)."""
     angles = sorted({float(a) for k, a in mapping.items() if 0 <= int(k) <= 63 and not math.isnan(float(a))})
     pos = {a: i for i, a in enumerate(angles)}
-    b2a = np.full(64, -1, np.int8)
+    b2a = np.full(64, -1, np.int16)
     for k, a in mapping.items():
         if 0 <= int(k) <= 63 and not math.isnan(float(a)):
             b2a[int(k)] = pos[float(a)]
     return b2a, np.array(angles, np.float64)
 
 
-def pivot_mean(ue, bs, rss, mapping: Dict[int, float]):
+def upscaled_axis(mapping: Dict[int, float], factor: int):
+    """The benchmark's "4x upscaled beam table" -- PARITY UNPINNED: the reference has no such mode (validate_beam_id
+    admits beams 0..63 only, excel_heatmap_v3.py:68-72), so this restates the build's own definition, not a
+    reference function.  The sorted distinct angles of the table are interpolated linearly to `factor` times as many
+    entries: entry factor*i is angle i exactly, entry factor*i + k lies k/factor of the way to angle i+1, and the
+    entries after the last angle continue its last step.  A beam whose angle is the i-th distinct one sits at entry
+    factor*i.  Returns (beam_to_axis int16[64], angles f64)."""
+    b2a, angles = axis_from_mapping(mapping)
+    n = len(angles)
+    if factor == 1 or n == 0:
+        return b2a, angles
+    up = np.empty(n * factor, np.float64)
+    for j in range(n * factor):
+        x = np.float64(j) / np.float64(factor)
+        if n == 1:
+            up[j] = angles[0] + x
+        else:
+            i0 = min(j // factor, n - 2)
+            up[j] = angles[i0] + (x - np.float64(i0)) * (angles[i0 + 1] - angles[i0])
+    up[::factor] = angles
+    return np.where(b2a >= 0, b2a.astype(np.int64) * factor, -1).astype(np.int16), up
+
+
+def pivot_mean(ue, bs, rss, mapping: Dict[int, float], upscale: int = 1):
     """map_angles (:264-280) + compute_rssi_matrix (:286-314).
 
     Returns (matrix f64 [n_aod, n_aoa] with NaN for empty cells, aod_list, aoa_list,
     sum int64 [n_axis,n_axis], cnt int64 [n_axis,n_axis]).  Axes hold only angles that occur.
+    upscale > 1 (parity unpinned, see upscaled_axis): the table is the up-scaled one and the matrix is the full
+    grid, every entry of the table a row and a column whether data fell on it or not.
     """
-    b2a, angles = axis_from_mapping(mapping)
+    b2a, angles = upscaled_axis(mapping, int(upscale))
     n_axis = len(angles)
     u, b, r = map(_i64, (ue, bs, rss))
     s = np.zeros((n_axis, n_axis), np.int64)
@@ -327,6 +352,8 @@ def pivot_mean(ue, bs, rss, mapping: Dict[int, float]):
         _L().orc_pivot(_ptr(u), _ptr(b), _ptr(r), len(u), _ptr(b2a), n_axis, _ptr(s), _ptr(c))
     rows = np.flatnonzero(c.sum(axis=1) > 0)
     cols = np.flatnonzero(c.sum(axis=0) > 0)
+    if upscale > 1:
+        rows = cols = np.arange(n_axis)
     with np.errstate(invalid="ignore", divide="ignore"):
         full = np.where(c > 0, s.astype(np.float64) / c.astype(np.float64), np.nan)
     mat = full[np.ix_(rows, cols)]

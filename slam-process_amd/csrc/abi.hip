@@ -76,7 +76,7 @@ extern "C" int slam_ctx_destroy(slam_ctx *ctx)
 {
     if (!ctx) return SLAM_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();          // not the ctx's stream: a caller's stream handle may be gone by now
     for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -110,9 +110,27 @@ extern "C" int slam_sync(slam_ctx *ctx)
 
 extern "C" const char *slam_last_error(slam_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
+// true while the ctx's stream is being captured into a graph: nothing may synchronise, allocate or free then, and
+// addresses baked into captured kernel nodes must stay valid for the graph's lifetime
+static bool stream_is_capturing(slam_ctx *ctx)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
 int slam_ws_reserve(slam_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_size) return SLAM_OK;
+    if (ctx->ws_pinned)
+        return slam_fail(ctx, SLAM_E_CAPACITY,
+                         "this call needs %zu bytes of workspace but the ctx's workspace (%zu bytes) is pinned by "
+                         "slam_pin_workspace: growing it would invalidate graphs captured on it (use another ctx, or unpin)",
+                         bytes, ctx->ws_size);
+    if (stream_is_capturing(ctx))
+        return slam_fail(ctx, SLAM_E_INVALID,
+                         "the workspace would have to grow to %zu bytes while the stream is being captured: call "
+                         "slam_reserve_workspace before the capture", bytes);
     SLAM_HIP(ctx, hipSetDevice(ctx->device));
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws) SLAM_HIP(ctx, hipFree(ctx->ws));
@@ -154,6 +172,10 @@ static int get_kernel(slam_ctx *ctx, double sigma, double **kern, int *ks)
         std::vector<double> k;
         int size = slam_gaussian_kernel_host(sigma, k);
         if (size > KMAX) return slam_fail(ctx, SLAM_E_RANGE, "blur sigma %.3f needs a %d-tap kernel (max %d)", sigma, size, KMAX);
+        if (stream_is_capturing(ctx) || ctx->ws_pinned)      // the upload synchronises and rewrites what captured nodes read
+            return slam_fail(ctx, SLAM_E_INVALID,
+                             "blur sigma %.3f differs from the one reserved (%.3f): not while the stream is captured or the "
+                             "workspace is pinned (slam_reserve_workspace with this batch first)", sigma, ctx->kern_sigma);
         SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         SLAM_HIP(ctx, hipMemcpy(ctx->kern_dev, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->kern_sigma = sigma;
@@ -604,10 +626,10 @@ extern "C" int slam_correct(slam_ctx *ctx, const int32_t *flag, const int32_t *u
 // a9-a10: pivot
 // ------------------------------------------------------------------------------------------------------
 extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const int32_t *rss, size_t n,
-                               const int8_t *beam_to_axis, int n_axis, int64_t *sum, int64_t *cnt, double *matrix)
+                               const int16_t *beam_to_axis, int n_axis, int64_t *sum, int64_t *cnt, double *matrix)
 {
     REQUIRE_CTX(ctx);
-    if (!beam_to_axis || n_axis < 1 || n_axis > 64) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: bad axis table");
+    if (!beam_to_axis || n_axis < 1 || n_axis > SLAM_MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: bad axis table");
     if (n && (!ue || !bs || !rss)) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean: null column");
     if (n > 0x7FFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "too many rows");
     for (int i = 0; i < 64; i++)
@@ -617,23 +639,23 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     const uint32_t row_cap = round16(n + 16);
     const int cells = n_axis * n_axis;
     ws_plan p;
-    size_t oc[3], ostat = p.add(SLAM_STAT_WORDS * 4), ob2a = p.add(64), omat = p.add(4096 * 8), ocnt64 = p.add(4096 * 8), rw[5];
+    size_t oc[3], ostat = p.add(SLAM_STAT_WORDS * 4), ob2a = p.add(64 * sizeof(int16_t)), omat = p.add((size_t)cells * 8), rw[10];
     for (int i = 0; i < 3; i++) oc[i] = p.add((size_t)row_cap * 4);
-    render_ws::plan(p, 1, 1, 1, rw);
+    render_ws::plan(p, 1, 1, 1, n_axis, rw);
     SLAM_TRY(slam_ws_reserve(ctx, p.total));
     uint8_t *b = ctx->ws;
     render_ws ws;
-    ws.bind(b, rw);
+    ws.bind(b, rw, n_axis);
     uint32_t *stats = (uint32_t *)(b + ostat);
     const int32_t *cols[3] = {ue, bs, rss};
     for (int i = 0; i < 3; i++) SLAM_TRY(h2d(ctx, b + oc[i], cols[i], n * 4));
-    SLAM_TRY(h2d(ctx, b + ob2a, beam_to_axis, 64));
+    SLAM_TRY(h2d(ctx, b + ob2a, beam_to_axis, 64 * sizeof(int16_t)));
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memset(ctx->pinned, 0, SLAM_STAT_WORDS * 4);
     ctx->pinned[SLAM_STAT_KEPT] = (uint32_t)n;
     SLAM_TRY(h2d(ctx, stats, ctx->pinned, SLAM_STAT_WORDS * 4));
     render_params rp{};
-    rp.beam_to_axis = (const int8_t *)(b + ob2a);
+    rp.beam_to_axis = (const int16_t *)(b + ob2a);
     rp.n_axis = n_axis;
     SLAM_TRY((pivot_accumulate<int32_t, int32_t>(ctx, (int32_t *)(b + oc[0]), (int32_t *)(b + oc[1]),
                                                  (int32_t *)(b + oc[2]), row_cap, 1, stats, SLAM_STAT_KEPT, rp, ws)));
@@ -644,7 +666,6 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     if (matrix) SLAM_TRY(d2h(ctx, matrix, b + omat, (size_t)cells * 8));
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (cnt) for (int i = 0; i < cells; i++) cnt[i] = c32[i];
-    (void)ocnt64;
     return SLAM_OK;
 }
 
@@ -679,12 +700,14 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
                            uint8_t *tile_rgba, int W, int H, double *vmin_vmax_out)
 {
     REQUIRE_CTX(ctx);
-    if (!mat || !aod || !aoa || !lut256x3 || h < 1 || w < 1 || h > 64 || w > 64)
-        return slam_fail(ctx, SLAM_E_INVALID, "slam_render: matrix must be 1..64 x 1..64 with axis lists and a LUT");
+    if (!mat || !aod || !aoa || !lut256x3 || h < 1 || w < 1 || h > SLAM_MAX_AXIS || w > SLAM_MAX_AXIS)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_render: matrix must be 1..%d x 1..%d with axis lists and a LUT",
+                         SLAM_MAX_AXIS, SLAM_MAX_AXIS);
     if (tile_rgba && (W < 1 || H < 1 || W > 16384 || H > 16384)) return slam_fail(ctx, SLAM_E_INVALID, "slam_render: bad tile size");
     if (!tile_rgba) { W = 1; H = 1; }
     ws_plan p;
-    size_t om = p.add((size_t)h * w * 8), oa = p.add(64 * 8), ob = p.add(64 * 8), ol = p.add(768), oc = p.add(4096 * 4),
+    size_t om = p.add((size_t)h * w * 8), oa = p.add(SLAM_MAX_AXIS * 8), ob = p.add(SLAM_MAX_AXIS * 8), ol = p.add(768),
+           oc = p.add((size_t)h * w * 4),
            ocm = p.add((size_t)W * 2), orm = p.add((size_t)H * 2), ost = p.add(SLAM_STAT_WORDS * 4),
            ot = p.add((size_t)W * H * 4);
     SLAM_TRY(slam_ws_reserve(ctx, p.total));
@@ -717,7 +740,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[6], cw[16], rw[5], tc, tb[3];
+    size_t fw[6], cw[16], rw[10], tc, tb[3];
     uint32_t nt_max, st_max, bl_cap;
     size_t total;
 };
@@ -745,21 +768,23 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
     bp.bl_cap = correct_ws::default_bl_cap(bt->row_cap);
     frame_ws::plan(p, bt->n_frames, bp.nt_max, bp.fw);
     correct_ws::plan(p, bt->n_frames, bt->row_cap, bp.bl_cap, bp.cw);
-    render_ws::plan(p, bt->n_frames, bt->tile_w, bt->tile_h, bp.rw);
+    render_ws::plan(p, bt->n_frames, bt->tile_w, bt->tile_h, bt->n_axis, bp.rw);
     bp.total = p.total;
     return SLAM_OK;
 }
 
 extern "C" int slam_raster_dev(slam_ctx *ctx, const uint8_t *cells_dev, const int16_t *colmap_dev,
                                const int16_t *rowmap_dev, const uint32_t *stats_dev, uint32_t n_frames,
-                               int32_t tile_w, int32_t tile_h, uint8_t *tile_dev)
+                               int32_t tile_w, int32_t tile_h, uint8_t *tile_dev, uint32_t cells_per_frame)
 {
     REQUIRE_CTX(ctx);
     if (!cells_dev || !colmap_dev || !rowmap_dev || !stats_dev || !tile_dev || tile_w < 1 || tile_h < 1)
         return slam_fail(ctx, SLAM_E_INVALID, "slam_raster_dev: NULL pointer or empty tile");
     if (((uintptr_t)tile_dev & 15u) || ((uintptr_t)cells_dev & 3u))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_raster_dev: tile must be 16-byte aligned, cells 4-byte aligned");
-    return raster_only(ctx, cells_dev, colmap_dev, rowmap_dev, stats_dev, n_frames, tile_w, tile_h, tile_dev);
+    if (cells_per_frame == 0 || cells_per_frame > (uint32_t)SLAM_MAX_AXIS * SLAM_MAX_AXIS)
+        return slam_fail(ctx, SLAM_E_INVALID, "slam_raster_dev: cells_per_frame must be slam_cells_per_frame(n_axis)");
+    return raster_only(ctx, cells_dev, colmap_dev, rowmap_dev, stats_dev, n_frames, tile_w, tile_h, tile_dev, cells_per_frame);
 }
 
 extern "C" size_t slam_batch_sizeof(void) { return sizeof(slam_batch); }
@@ -783,7 +808,7 @@ static int check_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages)
     if ((stages & 2u) && (!bt->kept_ue_dev || !bt->kept_bs_dev || !bt->kept_rss_dev || !bt->kept_clk_dev))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: corrected-row arrays are required");
     if ((stages & 4u) && (!bt->beam_to_axis_dev || !bt->axis_angle_dev || !bt->lut_dev || bt->n_axis < 1 ||
-                          bt->n_axis > 64 || (bt->tile_dev && (bt->tile_w < 1 || bt->tile_h < 1))))
+                          bt->n_axis > SLAM_MAX_AXIS || (bt->tile_dev && (bt->tile_w < 1 || bt->tile_h < 1))))
         return slam_fail(ctx, SLAM_E_INVALID, "slam_batch: render stage needs the axis table, LUT and tile size");
     if (((uintptr_t)bt->flag_dev | (uintptr_t)bt->ue_dev | (uintptr_t)bt->bs_dev | (uintptr_t)bt->rss_dev |
          (uintptr_t)bt->clk_dev) & 15u)
@@ -804,7 +829,7 @@ static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const
     correct_ws cws;
     cws.bind(b, bp.cw, bp.bl_cap);
     render_ws rws;
-    rws.bind(b, bp.rw);
+    rws.bind(b, bp.rw, bt->n_axis);
     if (bt->cells_dev) rws.cells = bt->cells_dev;
     if (bt->colmap_dev) rws.colmap = bt->colmap_dev;
     if (bt->rowmap_dev) rws.rowmap = bt->rowmap_dev;
@@ -840,13 +865,20 @@ static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const
     }
     if (stages & 4u) {
         render_params rp{bt->beam_to_axis_dev, bt->axis_angle_dev, bt->n_axis, bt->blur_sigma, bt->use_log,
-                         bt->vmin, bt->vmax, bt->lut_dev, bt->tile_w, bt->tile_h};
+                         bt->vmin, bt->vmax, bt->lut_dev, bt->tile_w, bt->tile_h, bt->full_grid ? 1 : 0};
         SLAM_TRY((pivot_accumulate<uint8_t, uint32_t>(ctx, bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev,
                                                       bt->row_cap, F, bt->stats_dev, SLAM_STAT_ROW_SLOTS, rp, rws,
                                                       kept_cnt, kept_stride)));
         SLAM_TRY(matrix_blur_render(ctx, F, rp, rws, kern, ks, bt->matrix_dev, bt->blurred_dev, bt->tile_dev,
                                     bt->stats_dev));
     }
+    return SLAM_OK;
+}
+
+extern "C" int slam_pin_workspace(slam_ctx *ctx, int pinned)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    ctx->ws_pinned = pinned != 0;
     return SLAM_OK;
 }
 

@@ -29,6 +29,7 @@ struct slam_ctx {
     uint8_t *ws = nullptr;
     size_t ws_size = 0;
     size_t ws_used = 0;
+    bool ws_pinned = false;     // slam_pin_workspace: calls that would grow (reallocate) the workspace fail instead
     // pinned host staging for small read-backs
     uint32_t *pinned = nullptr;
     // Gaussian blur kernel cached on the device

@@ -826,6 +826,21 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
     if (unsync) st[SLAM_STAT_TWO_PASS] = 1;
 }
 
+// A frame whose text is not in the strict capture format was decoded from characters that are not what they were
+// taken for: it ends up with no rows at all (no entries to walk, both counters zero), so every later stage sees an
+// empty frame and only NOT_STRICT tells the caller to send the text through the general tokenizer.
+__global__ __launch_bounds__(256) void k_frame_void_loose(uint32_t F, uint32_t *stats)
+{
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    if (st[SLAM_STAT_NOT_STRICT]) {
+        st[SLAM_STAT_VALID] = 0;
+        st[SLAM_STAT_DISCARDED] = 0;
+        st[SLAM_STAT_ROW_SLOTS] = 0;
+    }
+}
+
 }  // namespace
 
 uint32_t frame_tiles_for(int mode, uint32_t max_src_len)
@@ -938,5 +953,7 @@ int frame_decode(slam_ctx *ctx, int mode, const frame_src &src_in, uint32_t F, u
         SLAM_LAUNCH(ctx, "frame_emit", (k_frame_emit<SRC_RAW>), grid, block, src, nt_max, ws.tile_entry,
                     ws.tile_off, out, gate);
     }
+    if (mode == SRC_TEXT3 && slotted)          // the dense callers read NOT_STRICT themselves and decode again
+        SLAM_LAUNCH(ctx, "frame_void_loose", k_frame_void_loose, dim3((F + 255) / 256), dim3(256), F, stats);
     return SLAM_OK;
 }

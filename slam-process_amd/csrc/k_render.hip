@@ -19,8 +19,9 @@ namespace {
 // outside the room bypass the accumulator.  Fewer, larger chunks mean fewer flushes of 4096 cells each.
 template <typename T32> struct pivot_chunk { static constexpr int log2 = 16; };
 template <> struct pivot_chunk<uint32_t> { static constexpr int log2 = 18; };
-constexpr int MAX_AXIS = 64;
+constexpr int MAX_AXIS = SMALL_AXIS;                 // the LDS-resident path: at most 64 x 64 cells
 constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
+constexpr int N_BEAMS = 64;                          // beam ids are 6 bit (validate_beam_id, excel_heatmap_v3.py:68-72)
 
 template <typename T>
 struct v4;
@@ -33,26 +34,28 @@ struct v4<int32_t> { using type = int4; };
 
 template <typename T8, typename T32>
 __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
-                                                const uint32_t *stats, int stat_word, const int8_t *beam_to_axis,
-                                                int n_axis, unsigned long long *gsum, uint32_t *gcnt,
+                                                const uint32_t *stats, int stat_word, const int16_t *beam_to_axis,
+                                                int n_axis, uint32_t cell_stride, unsigned long long *gsum, uint32_t *gcnt,
                                                 const uint32_t *slot_cnt, uint32_t slot_stride)
 {
-    // One packed accumulator per cell: count at the top, sum below (see pivot_chunk).  Rows are padded to 65
-    // cells: consecutive BS beams at one UE beam are n_axis cells apart, which would put a whole wave on one LDS bank.
+    // One packed accumulator per (BS beam, UE beam) pair: count at the top, sum below (see pivot_chunk).  Rows are
+    // accumulated in beam space, whatever the size of the axis table; the beam -> axis mapping is applied once per
+    // pair when the workgroup flushes (pairs with an unmapped beam are dropped there, map_angles :275).  Rows are
+    // padded to 65 entries: consecutive BS beams at one UE beam would otherwise put a whole wave on one LDS bank.
     constexpr int CHUNK_LOG2 = pivot_chunk<T32>::log2, PIVOT_CHUNK = 1 << CHUNK_LOG2, SHIFT = 63 - CHUNK_LOG2;
     constexpr int64_t ROW_LIMIT = 1ll << (SHIFT - CHUNK_LOG2);
     constexpr int NH = 4;                  // groups of four entries per thread and step
     static_assert(PIVOT_CHUNK % (4096 * NH) == 0, "a step covers 4096 * NH entries");
-    constexpr int LSTRIDE = MAX_AXIS + 1;
-    __shared__ unsigned long long acc[MAX_AXIS * LSTRIDE];
-    __shared__ int8_t b2a[64];
+    constexpr int LSTRIDE = N_BEAMS + 1;
+    __shared__ unsigned long long acc[N_BEAMS * LSTRIDE];
+    __shared__ int16_t b2a[N_BEAMS];
     const uint32_t f = blockIdx.y, tid = threadIdx.x;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + stat_word];
     const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
     if (r0 >= n) return;
     const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
-    for (int i = tid; i < n_axis * LSTRIDE; i += 1024) acc[i] = 0;
-    if (tid < 64) b2a[tid] = beam_to_axis[tid];
+    for (int i = tid; i < N_BEAMS * LSTRIDE; i += 1024) acc[i] = 0;
+    if (tid < N_BEAMS) b2a[tid] = beam_to_axis[tid];
     __syncthreads();
     const size_t fb = (size_t)f * row_cap;
     using V8 = typename v4<T8>::type;
@@ -89,25 +92,27 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
             for (int k = 0; k < 4; k++) {
                 if (i0 + k >= lim[h]) break;
                 if (uu[k] < 0 || uu[k] > 63 || bb[k] < 0 || bb[k] > 63) continue;     // validate_beam_id (:68-72)
-                int c = b2a[uu[k]], rw = b2a[bb[k]];
-                // unmapped beam (-1) dropped (:275); an index at or past n_axis cannot come from a valid table
-                if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
                 if (rr[k] >= 0 && rr[k] < ROW_LIMIT) {
-                    atomicAdd(&acc[rw * LSTRIDE + c], (unsigned long long)rr[k] | (1ull << SHIFT));
+                    atomicAdd(&acc[bb[k] * LSTRIDE + uu[k]], (unsigned long long)rr[k] | (1ull << SHIFT));
                 } else {                                                             // no room in the packed sum
-                    atomicAdd(&gsum[(size_t)f * MAX_CELLS + rw * n_axis + c], (unsigned long long)rr[k]);
-                    atomicAdd(&gcnt[(size_t)f * MAX_CELLS + rw * n_axis + c], 1u);
+                    const int c = b2a[uu[k]], rw = b2a[bb[k]];
+                    if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
+                    atomicAdd(&gsum[(size_t)f * cell_stride + rw * n_axis + c], (unsigned long long)rr[k]);
+                    atomicAdd(&gcnt[(size_t)f * cell_stride + rw * n_axis + c], 1u);
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < n_axis * n_axis; i += 1024) {
-        const unsigned long long a = acc[(i / n_axis) * LSTRIDE + (i % n_axis)];
-        if (a >> SHIFT) {
-            atomicAdd(&gsum[(size_t)f * MAX_CELLS + i], a & ((1ull << SHIFT) - 1));
-            atomicAdd(&gcnt[(size_t)f * MAX_CELLS + i], (uint32_t)(a >> SHIFT));
-        }
+    for (int i = tid; i < N_BEAMS * N_BEAMS; i += 1024) {
+        const int bb = i >> 6, uu = i & 63;
+        const unsigned long long a = acc[bb * LSTRIDE + uu];
+        if (!(a >> SHIFT)) continue;
+        // unmapped beam (-1) dropped (:275); an index at or past n_axis cannot come from a valid table
+        const int c = b2a[uu], rw = b2a[bb];
+        if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
+        atomicAdd(&gsum[(size_t)f * cell_stride + rw * n_axis + c], a & ((1ull << SHIFT) - 1));
+        atomicAdd(&gcnt[(size_t)f * cell_stride + rw * n_axis + c], (uint32_t)(a >> SHIFT));
     }
 }
 
@@ -115,28 +120,33 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
 
 __device__ __forceinline__ bool finite_d(double v) { return !(isnan(v) || isinf(v)); }
 
-// out[i*w+j] = normalised convolution of in (h x w, row stride w) with kern (ks x ks), edge padding.
-__device__ void blur_block(const double *in, int h, int w, const double *kern, int ks, double *out)
+// Cell c of the normalised convolution of in (h x w, row stride w) with kern (ks x ks), edge padding
+// (gaussian_blur_nan_aware :336-368, taps in the reference's row-major order).
+__device__ __forceinline__ double blur_cell(const double *in, int h, int w, const double *kern, int ks, int c)
 {
     const int p = ks / 2;
-    for (int c = threadIdx.x; c < h * w; c += blockDim.x) {
-        const int i = c / w, j = c % w;
-        double num = 0.0, den = 0.0;
-        for (int a = 0; a < ks; a++) {
-            int ii = i + a - p;
-            ii = ii < 0 ? 0 : (ii >= h ? h - 1 : ii);
-            for (int b = 0; b < ks; b++) {
-                int jj = j + b - p;
-                jj = jj < 0 ? 0 : (jj >= w ? w - 1 : jj);
-                const double v = in[ii * w + jj];
-                const bool fin = finite_d(v);
-                const double wgt = kern[a * ks + b] * (fin ? 1.0 : 0.0);
-                num += (fin ? v : 0.0) * wgt;
-                den += wgt;
-            }
+    const int i = c / w, j = c % w;
+    double num = 0.0, den = 0.0;
+    for (int a = 0; a < ks; a++) {
+        int ii = i + a - p;
+        ii = ii < 0 ? 0 : (ii >= h ? h - 1 : ii);
+        for (int b = 0; b < ks; b++) {
+            int jj = j + b - p;
+            jj = jj < 0 ? 0 : (jj >= w ? w - 1 : jj);
+            const double v = in[ii * w + jj];
+            const bool fin = finite_d(v);
+            const double wgt = kern[a * ks + b] * (fin ? 1.0 : 0.0);
+            num += (fin ? v : 0.0) * wgt;
+            den += wgt;
         }
-        out[c] = den > 1e-12 ? num / den : __longlong_as_double(0x7FF8000000000000ll);
     }
+    return den > 1e-12 ? num / den : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+// the whole matrix by one workgroup
+__device__ void blur_block(const double *in, int h, int w, const double *kern, int ks, double *out)
+{
+    for (int c = threadIdx.x; c < h * w; c += blockDim.x) out[c] = blur_cell(in, h, w, kern, ks, c);
 }
 
 // finite min / max of m[0..n) across the block (blockDim.x a power of two <= 1024); sh needs 2*blockDim.x
@@ -226,29 +236,36 @@ __device__ bool scale_limits(int use_log, double vmin, double vmax, double mn, d
 }
 
 // Cell colours for limits from scale_limits: index = floor(norm * 256) clipped to the table, holes transparent.
+struct colour_scale { int use_log; double mn, lo, tlo, span; };
+
+__device__ __forceinline__ colour_scale make_scale(int use_log, double mn, double lo, double hi)
+{
+    colour_scale s{use_log, mn, lo, 0.0, 0.0};
+    if (use_log) {
+        s.tlo = log10(lo);
+        s.span = log10(hi) - s.tlo;
+    } else {
+        s.span = hi - lo;
+    }
+    return s;
+}
+
+__device__ __forceinline__ uchar4 colour_of(double v, const colour_scale &s, const uint8_t *lut)
+{
+    if (!finite_d(v)) return make_uchar4(255, 255, 255, 0);      // set_bad((1,1,1,0)) (:447)
+    double nrm;
+    if (s.use_log) nrm = (log10(v - s.mn + 1e-6) - s.tlo) / s.span;
+    else nrm = (v - s.lo) / s.span;
+    const double x = floor(nrm * 256.0);
+    const int idx = isnan(x) ? 0 : (x < 0.0 ? 0 : (x > 255.0 ? 255 : (int)x));
+    return make_uchar4(lut[idx * 3], lut[idx * 3 + 1], lut[idx * 3 + 2], 255);
+}
+
 __device__ void colour_block(const double *m, int h, int w, int use_log, double mn, double lo, double hi,
                              const uint8_t *lut, uint8_t *cells)
 {
-    double tlo = 0.0, span;
-    if (use_log) {
-        tlo = log10(lo);
-        span = log10(hi) - tlo;
-    } else {
-        span = hi - lo;
-    }
-    for (int c = threadIdx.x; c < h * w; c += blockDim.x) {
-        const double v = m[c];
-        uchar4 px = make_uchar4(255, 255, 255, 0);           // set_bad((1,1,1,0)) (:447)
-        if (finite_d(v)) {
-            double nrm;
-            if (use_log) nrm = (log10(v - mn + 1e-6) - tlo) / span;
-            else nrm = (v - lo) / span;
-            double x = floor(nrm * 256.0);
-            int idx = isnan(x) ? 0 : (x < 0.0 ? 0 : (x > 255.0 ? 255 : (int)x));
-            px = make_uchar4(lut[idx * 3], lut[idx * 3 + 1], lut[idx * 3 + 2], 255);
-        }
-        reinterpret_cast<uchar4 *>(cells)[c] = px;
-    }
+    const colour_scale s = make_scale(use_log, mn, lo, hi);
+    for (int c = threadIdx.x; c < h * w; c += blockDim.x) reinterpret_cast<uchar4 *>(cells)[c] = colour_of(m[c], s, lut);
 }
 
 __device__ __forceinline__ void put_f64_stat(uint32_t *stats, int lo_word, double v)
@@ -270,10 +287,11 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
     __shared__ int s_h, s_w;
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const int na = rp.n_axis;
-    const unsigned long long *sum = ws.sum + (size_t)f * MAX_CELLS;
-    const uint32_t *cnt = ws.cnt + (size_t)f * MAX_CELLS;
+    const unsigned long long *sum = ws.sum + (size_t)f * ws.cell_stride;
+    const uint32_t *cnt = ws.cnt + (size_t)f * ws.cell_stride;
     uint32_t *st = stats + f * SLAM_STAT_WORDS;
-    if (tid < MAX_AXIS) { rowp[tid] = 0; colp[tid] = 0; }
+    // full_grid: every entry of the axis table is a row and a column whether any row of data fell on it or not
+    if (tid < MAX_AXIS) { rowp[tid] = rp.full_grid ? 1u : 0u; colp[tid] = rp.full_grid ? 1u : 0u; }
     __syncthreads();
     for (int c = tid; c < na * na; c += 1024) {
         const uint32_t k = cnt[c];
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
     double mn, mx;
     __syncthreads();
     const bool any = block_minmax(fin, h * w, fin == cm ? bm : cm, &mn, &mx);     // the grid not in use is the scratch
-    uint8_t *cells = ws.cells + (size_t)f * MAX_CELLS * 4;
+    uint8_t *cells = ws.cells + (size_t)f * ws.cell_stride * 4;
     if (!any) {
         if (tid == 0) st[SLAM_STAT_ALLNAN] = 1;
         return;
@@ -325,7 +343,11 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
         return;
     }
     colour_block(fin, h, w, rp.use_log, mn, lo, hi, rp.lut, cells);
-    if (tid == 0) { put_f64_stat(st, SLAM_STAT_VMIN_LO, lo); put_f64_stat(st, SLAM_STAT_VMAX_LO, hi); }
+    if (tid == 0) {
+        put_f64_stat(st, SLAM_STAT_VMIN_LO, lo);
+        put_f64_stat(st, SLAM_STAT_VMAX_LO, hi);
+        st[SLAM_STAT_ALLNAN] = 0;                  // a render that succeeds clears what an earlier one on these words left
+    }
     if (tid == 0) edges_of(ang_c, w, edge);
     __syncthreads();
     axis_map(edge, w, rp.W, false, ws.colmap + (size_t)f * rp.W);
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_frame_matrix(render_params rp, render_
 // band moves to another cell row (a cell covers many pixel rows), so the kernel is a stream of 16-byte stores.
 constexpr int RASTER_BAND = 16;
 __global__ __launch_bounds__(256) void k_raster(const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap,
-                                                 int W, int H, const uint32_t *stats, uint8_t *tile)
+                                                 int W, int H, const uint32_t *stats, uint8_t *tile, uint32_t cell_stride)
 {
     const uint32_t f = blockIdx.z;
     const uint32_t px0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(256) void k_raster(const uint8_t *cells, const int1
     const uint32_t *st = stats + f * SLAM_STAT_WORDS;
     const bool blank = st[SLAM_STAT_ALLNAN] != 0;
     const int w = (int)st[SLAM_STAT_N_AOA];
-    const uint32_t *c4 = reinterpret_cast<const uint32_t *>(cells) + (size_t)f * MAX_CELLS;
+    const uint32_t *c4 = reinterpret_cast<const uint32_t *>(cells) + (size_t)f * cell_stride;
     int col[4] = {0, 0, 0, 0};
     const int npx = min(4, W - (int)px0);
     if (!blank)
@@ -374,12 +396,142 @@ __global__ __launch_bounds__(256) void k_raster(const uint8_t *cells, const int1
     }
 }
 
+// ---- wide axis tables (65 .. 256 entries): the same steps as k_frame_matrix with the grids in global memory ------
+// k_wide_mean -> k_wide_axes -> k_wide_compact -> k_wide_blur -> k_wide_colour; all but k_wide_axes run one cell per
+// thread over grid (cells / 256, frames).
+
+// finite doubles <-> u64 keys that order like the values (for atomicMin / atomicMax)
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+
+__global__ __launch_bounds__(256) void k_wide_mean(render_params rp, render_ws ws, double *matrix)
+{
+    const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t na = (uint32_t)rp.n_axis;
+    if (c >= na * na) return;
+    const uint32_t k = ws.cnt[(size_t)f * ws.cell_stride + c];
+    const double mean = k ? (double)(long long)ws.sum[(size_t)f * ws.cell_stride + c] / (double)k
+                          : __longlong_as_double(0x7FF8000000000000ll);
+    ws.grid_b[(size_t)f * ws.cell_stride + c] = mean;
+    if (matrix) matrix[(size_t)f * na * na + c] = mean;
+    if (k) {                                       // every writer stores the same value
+        ws.present[(size_t)f * 2 * WIDE_AXIS + c / na] = 1u;
+        ws.present[(size_t)f * 2 * WIDE_AXIS + WIDE_AXIS + c % na] = 1u;
+    }
+}
+
+// One workgroup of 256 threads per frame: the axes that occur (or all of them), their index lists, _edges and the
+// pixel -> cell maps; clears the frame's min / max keys.
+__global__ __launch_bounds__(256) void k_wide_axes(render_params rp, render_ws ws, uint32_t *stats)
+{
+    __shared__ double ang_r[WIDE_AXIS], ang_c[WIDE_AXIS], edge[WIDE_AXIS + 1];
+    __shared__ uint32_t sh[17];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const int na = rp.n_axis;
+    uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    const uint32_t *pres = ws.present + (size_t)f * 2 * WIDE_AXIS;
+    int16_t *ridx = ws.axis_idx + (size_t)f * 2 * WIDE_AXIS, *cidx = ridx + WIDE_AXIS;
+    const bool rp_ = (int)tid < na && (rp.full_grid || pres[tid]);
+    const bool cp_ = (int)tid < na && (rp.full_grid || pres[WIDE_AXIS + tid]);
+    uint32_t h, w;
+    const uint32_t kr = block_excl_scan(rp_ ? 1u : 0u, sh, &h);
+    const uint32_t kc = block_excl_scan(cp_ ? 1u : 0u, sh, &w);
+    if (rp_) { ridx[kr] = (int16_t)tid; ang_r[kr] = rp.axis_angle[tid]; }
+    if (cp_) { cidx[kc] = (int16_t)tid; ang_c[kc] = rp.axis_angle[tid]; }
+    if (tid == 0) {
+        st[SLAM_STAT_N_AOD] = h;
+        st[SLAM_STAT_N_AOA] = w;
+        st[SLAM_STAT_ALLNAN] = (h == 0 || w == 0) ? 1u : 0u;
+        ws.minmax[(size_t)f * 2] = ~0ull;
+        ws.minmax[(size_t)f * 2 + 1] = 0ull;
+    }
+    if (h == 0 || w == 0) return;
+    __syncthreads();
+    if (tid == 0) edges_of(ang_c, (int)w, edge);
+    __syncthreads();
+    axis_map(edge, (int)w, rp.W, false, ws.colmap + (size_t)f * rp.W);
+    __syncthreads();
+    if (tid == 0) edges_of(ang_r, (int)h, edge);
+    __syncthreads();
+    axis_map(edge, (int)h, rp.H, true, ws.rowmap + (size_t)f * rp.H);
+}
+
+// compact mean matrix (h x w, row stride w) out of the full grid
+__global__ __launch_bounds__(256) void k_wide_compact(render_params rp, render_ws ws, const uint32_t *stats)
+{
+    const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t h = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOD], w = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOA];
+    if (c >= h * w) return;
+    const int16_t *ridx = ws.axis_idx + (size_t)f * 2 * WIDE_AXIS, *cidx = ridx + WIDE_AXIS;
+    ws.grid_a[(size_t)f * ws.cell_stride + c] =
+        ws.grid_b[(size_t)f * ws.cell_stride + (uint32_t)ridx[c / w] * (uint32_t)rp.n_axis + (uint32_t)cidx[c % w]];
+}
+
+// blur (or copy, ks <= 1) of the compact matrix, the finite minimum / maximum of the result
+__global__ __launch_bounds__(256) void k_wide_blur(render_params rp, render_ws ws, const double *kern, int ks,
+                                                    double *blurred, const uint32_t *stats)
+{
+    const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t h = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOD], w = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOA];
+    if (blockIdx.x * 256 >= h * w) return;                          // whole workgroup past the matrix
+    const double *in = ws.grid_a + (size_t)f * ws.cell_stride;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    if (c < h * w) {
+        const double v = ks > 1 ? blur_cell(in, (int)h, (int)w, kern, ks, (int)c) : in[c];
+        ws.grid_b[(size_t)f * ws.cell_stride + c] = v;
+        if (blurred) blurred[(size_t)f * rp.n_axis * rp.n_axis + c] = v;
+        if (finite_d(v)) lo = hi = order_key(v);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long ol = shfl64(lo, (int)(lane_id() ^ d)), oh = shfl64(hi, (int)(lane_id() ^ d));
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if (lane_id() == 0 && lo <= hi) {
+        atomicMin(ws.minmax + (size_t)f * 2, lo);
+        atomicMax(ws.minmax + (size_t)f * 2 + 1, hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wide_colour(render_params rp, render_ws ws, uint32_t *stats)
+{
+    const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    const uint32_t h = st[SLAM_STAT_N_AOD], w = st[SLAM_STAT_N_AOA];
+    if (h == 0 || w == 0) return;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    const unsigned long long klo = ws.minmax[(size_t)f * 2], khi = ws.minmax[(size_t)f * 2 + 1];
+    if (klo > khi) {                                               // no finite cell
+        if (first) st[SLAM_STAT_ALLNAN] = 1;
+        return;
+    }
+    const double mn = key_value(klo), mx = key_value(khi);
+    double lo, hi;
+    if (!scale_limits(rp.use_log, rp.vmin, rp.vmax, mn, mx, &lo, &hi)) {
+        if (first) st[SLAM_STAT_ALLNAN] = 2;
+        return;
+    }
+    if (first) { put_f64_stat(st, SLAM_STAT_VMIN_LO, lo); put_f64_stat(st, SLAM_STAT_VMAX_LO, hi); }
+    if (c >= h * w) return;
+    const colour_scale s = make_scale(rp.use_log, mn, lo, hi);
+    reinterpret_cast<uchar4 *>(ws.cells + (size_t)f * ws.cell_stride * 4)[c] =
+        colour_of(ws.grid_b[(size_t)f * ws.cell_stride + c], s, rp.lut);
+}
+
 // ---- standalone stages on caller matrices ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_blur_only(const double *in, int h, int w, const double *kern, int ks,
                                                     double *out)
 {
-    // one workgroup; strides over all cells
-    blur_block(in, h, w, kern, ks, out);
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;         // one cell per thread over the whole grid
+    if (c < (size_t)h * w) out[c] = blur_cell(in, h, w, kern, ks, (int)c);
 }
 
 __global__ __launch_bounds__(256) void k_mean_only(const unsigned long long *sum, const uint32_t *cnt, int cells,
@@ -397,10 +549,10 @@ __global__ __launch_bounds__(256) void k_render_only(const double *mat, int h, i
                                                       int16_t *rowmap, int W, int H, uint32_t *stats)
 {
     __shared__ double red[512];
-    __shared__ double edge[MAX_AXIS + 1];
+    __shared__ double edge[WIDE_AXIS + 1];
     const uint32_t tid = threadIdx.x;
     double mn, mx;
-    if (tid == 0) { stats[SLAM_STAT_N_AOD] = h; stats[SLAM_STAT_N_AOA] = w; }
+    if (tid == 0) { stats[SLAM_STAT_N_AOD] = h; stats[SLAM_STAT_N_AOA] = w; stats[SLAM_STAT_ALLNAN] = 0; }
     const bool any = block_minmax(mat, h * w, red, &mn, &mx);
     if (!any) {
         if (tid == 0) stats[SLAM_STAT_ALLNAN] = 1;
@@ -424,22 +576,40 @@ __global__ __launch_bounds__(256) void k_render_only(const double *mat, int h, i
 
 }  // namespace
 
-void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, size_t off[5])
+extern "C" uint32_t slam_cells_per_frame(int32_t n_axis)
 {
-    off[0] = p.add((size_t)F * MAX_CELLS * 8);
-    off[1] = p.add((size_t)F * MAX_CELLS * 4);
-    off[2] = p.add((size_t)F * MAX_CELLS * 4);
-    off[3] = p.add((size_t)F * (size_t)(W > 0 ? W : 1) * 2);
-    off[4] = p.add((size_t)F * (size_t)(H > 0 ? H : 1) * 2);
+    return n_axis <= SMALL_AXIS ? (uint32_t)MAX_CELLS : (uint32_t)n_axis * (uint32_t)n_axis;
 }
 
-void render_ws::bind(uint8_t *base, const size_t off[5])
+void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[10])
+{
+    const size_t cells = slam_cells_per_frame(n_axis);
+    const bool wide = n_axis > SMALL_AXIS;
+    off[0] = p.add((size_t)F * cells * 8);
+    off[1] = p.add((size_t)F * cells * 4);
+    off[2] = p.add((size_t)F * cells * 4);
+    off[3] = p.add((size_t)F * (size_t)(W > 0 ? W : 1) * 2);
+    off[4] = p.add((size_t)F * (size_t)(H > 0 ? H : 1) * 2);
+    off[5] = p.add(wide ? (size_t)F * cells * 8 : 0);
+    off[6] = p.add(wide ? (size_t)F * cells * 8 : 0);
+    off[7] = p.add(wide ? (size_t)F * 2 * WIDE_AXIS * 4 : 0);
+    off[8] = p.add(wide ? (size_t)F * 2 * WIDE_AXIS * 2 : 0);
+    off[9] = p.add(wide ? (size_t)F * 2 * 8 : 0);
+}
+
+void render_ws::bind(uint8_t *base, const size_t off[10], int n_axis)
 {
     sum = (unsigned long long *)(base + off[0]);
     cnt = (uint32_t *)(base + off[1]);
     cells = base + off[2];
     colmap = (int16_t *)(base + off[3]);
     rowmap = (int16_t *)(base + off[4]);
+    grid_a = (double *)(base + off[5]);
+    grid_b = (double *)(base + off[6]);
+    present = (uint32_t *)(base + off[7]);
+    axis_idx = (int16_t *)(base + off[8]);
+    minmax = (unsigned long long *)(base + off[9]);
+    cell_stride = slam_cells_per_frame(n_axis);
 }
 
 template <typename T8, typename T32>
@@ -448,13 +618,13 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
                      const uint32_t *slot_cnt, uint32_t slot_stride)
 {
     if (F == 0) return SLAM_OK;
-    if (rp.n_axis < 1 || rp.n_axis > MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..64");
-    SLAM_TRY(slam_zero_async(ctx, ws.sum, (size_t)F * MAX_CELLS * 8));
-    SLAM_TRY(slam_zero_async(ctx, ws.cnt, (size_t)F * MAX_CELLS * 4));
+    if (rp.n_axis < 1 || rp.n_axis > WIDE_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..%d", WIDE_AXIS);
+    SLAM_TRY(slam_zero_async(ctx, ws.sum, (size_t)F * ws.cell_stride * 8));
+    SLAM_TRY(slam_zero_async(ctx, ws.cnt, (size_t)F * ws.cell_stride * 4));
     constexpr uint32_t chunk = 1u << pivot_chunk<T32>::log2;
     dim3 grid((row_cap + chunk - 1) / chunk, F), block(1024);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
-                rp.beam_to_axis, rp.n_axis, ws.sum, ws.cnt, slot_cnt, slot_stride);
+                rp.beam_to_axis, rp.n_axis, ws.cell_stride, ws.sum, ws.cnt, slot_cnt, slot_stride);
     return SLAM_OK;
 }
 
@@ -484,24 +654,38 @@ int slam_gaussian_kernel_host(double sigma, std::vector<double> &k)
     return size;
 }
 
+static dim3 raster_grid(int W, int H, uint32_t F)
+{
+    return dim3((uint32_t)((W + 1023) / 1024), (uint32_t)((H + RASTER_BAND - 1) / RASTER_BAND), F);
+}
+
 int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const render_ws &ws, const double *kern,
                        int ks, double *matrix, double *blurred, uint8_t *tile, uint32_t *stats)
 {
     if (F == 0) return SLAM_OK;
-    SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(1024), rp, ws, kern, ks, matrix, blurred, stats);
-    if (tile) {
-        const dim3 rgrid((uint32_t)((rp.W + 1023) / 1024), (uint32_t)((rp.H + RASTER_BAND - 1) / RASTER_BAND), F);
-        SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), ws.cells, ws.colmap, ws.rowmap, rp.W, rp.H, stats, tile);
+    if (rp.n_axis <= SMALL_AXIS) {
+        SLAM_LAUNCH(ctx, "frame_matrix", k_frame_matrix, dim3(F), dim3(1024), rp, ws, kern, ks, matrix, blurred, stats);
+    } else {
+        const dim3 cgrid((uint32_t)(rp.n_axis * rp.n_axis + 255) / 256, F), blk(256);
+        if (!rp.full_grid) SLAM_TRY(slam_zero_async(ctx, ws.present, (size_t)F * 2 * WIDE_AXIS * 4));
+        SLAM_LAUNCH(ctx, "wide_mean", k_wide_mean, cgrid, blk, rp, ws, matrix);
+        SLAM_LAUNCH(ctx, "wide_axes", k_wide_axes, dim3(F), blk, rp, ws, stats);
+        SLAM_LAUNCH(ctx, "wide_compact", k_wide_compact, cgrid, blk, rp, ws, stats);
+        SLAM_LAUNCH(ctx, "wide_blur", k_wide_blur, cgrid, blk, rp, ws, kern, ks, blurred, stats);
+        SLAM_LAUNCH(ctx, "wide_colour", k_wide_colour, cgrid, blk, rp, ws, stats);
     }
+    if (tile)
+        SLAM_LAUNCH(ctx, "raster", k_raster, raster_grid(rp.W, rp.H, F), dim3(256), ws.cells, ws.colmap, ws.rowmap, rp.W,
+                    rp.H, stats, tile, ws.cell_stride);
     return SLAM_OK;
 }
 
 int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap, const uint32_t *stats,
-                uint32_t F, int W, int H, uint8_t *tile)
+                uint32_t F, int W, int H, uint8_t *tile, uint32_t cell_stride)
 {
     if (F == 0) return SLAM_OK;
-    const dim3 rgrid((uint32_t)((W + 1023) / 1024), (uint32_t)((H + RASTER_BAND - 1) / RASTER_BAND), F);
-    SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), cells, colmap, rowmap, W, H, stats, tile);
+    SLAM_LAUNCH(ctx, "raster", k_raster, raster_grid(W, H, F), dim3(256), cells, colmap, rowmap, W, H, stats, tile,
+                cell_stride);
     return SLAM_OK;
 }
 
@@ -513,7 +697,8 @@ int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt,
 
 int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern, int ks, double *out)
 {
-    SLAM_LAUNCH(ctx, "blur", k_blur_only, dim3(1), dim3(256), in, h, w, kern, ks, out);
+    const size_t cells = (size_t)h * w;
+    SLAM_LAUNCH(ctx, "blur", k_blur_only, dim3((uint32_t)((cells + 255) / 256)), dim3(256), in, h, w, kern, ks, out);
     return SLAM_OK;
 }
 
@@ -523,9 +708,7 @@ int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *ao
 {
     SLAM_LAUNCH(ctx, "render_cells", k_render_only, dim3(1), dim3(256), mat, h, w, aod, aoa, use_log, vmin, vmax,
                 lut, cells, colmap, rowmap, W, H, stats);
-    if (tile) {
-        const dim3 rgrid((uint32_t)((W + 1023) / 1024), (uint32_t)((H + RASTER_BAND - 1) / RASTER_BAND), 1);
-        SLAM_LAUNCH(ctx, "raster", k_raster, rgrid, dim3(256), cells, colmap, rowmap, W, H, stats, tile);
-    }
+    if (tile)      // the cells of one matrix: the stride between frames plays no part
+        SLAM_LAUNCH(ctx, "raster", k_raster, raster_grid(W, H, 1), dim3(256), cells, colmap, rowmap, W, H, stats, tile, 0u);
     return SLAM_OK;
 }

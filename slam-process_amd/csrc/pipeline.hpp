@@ -142,8 +142,11 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                  uint32_t *stats);
 
 // ---- pivot / blur / raster ---------------------------------------------------------------------
+constexpr int SMALL_AXIS = 64;          // axis tables up to here: one workgroup per frame, grids in LDS (k_frame_matrix)
+constexpr int WIDE_AXIS = SLAM_MAX_AXIS; // larger tables (up to 256 entries): grids in global memory, several kernels
+
 struct render_params {
-    const int8_t *beam_to_axis;     // device [64]
+    const int16_t *beam_to_axis;    // device [64]
     const double *axis_angle;       // device [n_axis]
     int32_t n_axis;
     double sigma;
@@ -151,15 +154,22 @@ struct render_params {
     double vmin, vmax;
     const uint8_t *lut;             // device [768]
     int32_t W, H;
+    int32_t full_grid;              // 1: every entry of the axis table is a row and a column, occupied or not
 };
 
 struct render_ws {
-    unsigned long long *sum;        // [F * 4096]
-    uint32_t *cnt;                  // [F * 4096]
-    uint8_t *cells;                 // [F * 4096 * 4] RGBA per compact cell
+    unsigned long long *sum;        // [F * cells]   cells = slam_cells_per_frame(n_axis)
+    uint32_t *cnt;                  // [F * cells]
+    uint8_t *cells;                 // [F * cells * 4] RGBA per compact cell
     int16_t *colmap, *rowmap;       // [F * W], [F * H] pixel -> compact cell index
-    static void plan(ws_plan &p, uint32_t F, int W, int H, size_t off[5]);
-    void bind(uint8_t *base, const size_t off[5]);
+    // wide axis tables only
+    double *grid_a, *grid_b;        // [F * cells] full-grid mean / compact mean / blurred, in turn
+    uint32_t *present;              // [F * 2 * WIDE_AXIS] rows, then columns, that hold data
+    int16_t *axis_idx;              // [F * 2 * WIDE_AXIS] compact row -> axis entry, compact column -> axis entry
+    unsigned long long *minmax;     // [F * 2] order-preserving keys of the finite minimum / maximum
+    uint32_t cell_stride;           // cells per frame
+    static void plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[10]);
+    void bind(uint8_t *base, const size_t off[10], int n_axis);
 };
 
 // slot_cnt != nullptr: the rows are slotted per ROWS_PER_BLOCK entries (kept_out_t) and stat_word counts entries
@@ -179,7 +189,7 @@ int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *ao
                 double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,
                 int16_t *colmap, int16_t *rowmap, uint32_t *stats);
 int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, const int16_t *rowmap, const uint32_t *stats,
-                uint32_t F, int W, int H, uint8_t *tile);
+                uint32_t F, int W, int H, uint8_t *tile, uint32_t cell_stride);
 int slam_gaussian_kernel_host(double sigma, std::vector<double> &k);
 
 // ---- general tokenizer ---------------------------------------------------------------------------

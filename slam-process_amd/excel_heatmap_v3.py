@@ -205,7 +205,7 @@ def compute_rssi_matrix(df: pd.DataFrame, logger: Optional[logging.Logger] = Non
     r_idx = np.searchsorted(aod_vals, df["AoD"].to_numpy(np.float64))
     c_idx = np.searchsorted(aoa_vals, df["AoA"].to_numpy(np.float64))
     n_axis = max(len(aod_vals), len(aoa_vals))
-    ident = np.full(64, -1, np.int8)
+    ident = np.full(64, -1, np.int16)
     ident[:n_axis] = np.arange(n_axis)
     _s, _c, mean = ops.pivot_mean(c_idx, r_idx, rss.astype(np.int64), ident, n_axis)
     matrix = np.ascontiguousarray(mean[: len(aod_vals), : len(aoa_vals)])

@@ -22,12 +22,18 @@ STAT_WORDS = 16
  STAT_ROW_SLOTS, STAT_TWO_PASS) = range(16)
 TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
 NOALLOC_SCRATCH_BYTES = 64 << 20
+MAX_AXIS = 256
+
+
+def cells_per_frame(n_axis: int) -> int:
+    """slam_cells_per_frame: cells reserved per frame in the cell-colour buffers."""
+    return 4096 if n_axis <= 64 else n_axis * n_axis
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
-    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_batch_sizeof",
-    "slam_row_tiles", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
+    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
+    "slam_row_tiles", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
 
@@ -45,7 +51,7 @@ class Batch(C.Structure):
         ("text_dev", C.c_void_p), ("text_off_dev", C.c_void_p), ("text_len_dev", C.c_void_p),
         ("n_frames", C.c_uint32), ("max_text_len", C.c_uint32), ("src_is_bytes", C.c_uint32),
         ("cycle", C.c_int32), ("tol", C.c_int32), ("mod_base", C.c_int32),
-        ("beam_to_axis_dev", C.c_void_p), ("axis_angle_dev", C.c_void_p), ("n_axis", C.c_int32),
+        ("beam_to_axis_dev", C.c_void_p), ("axis_angle_dev", C.c_void_p), ("n_axis", C.c_int32), ("full_grid", C.c_int32),
         ("blur_sigma", C.c_double), ("use_log", C.c_int32), ("vmin", C.c_double), ("vmax", C.c_double),
         ("lut_dev", C.c_void_p), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("row_cap", C.c_uint32),
@@ -104,11 +110,14 @@ def load() -> C.CDLL:
         lib.slam_process_frames_dev.argtypes = [vp, C.POINTER(Batch), u32]
         lib.slam_process_frames_noalloc_dev.argtypes = [vp, C.POINTER(Batch), u32]
         lib.slam_reserve_workspace.argtypes = [vp, C.POINTER(Batch)]
+        lib.slam_pin_workspace.argtypes = [vp, C.c_int]
         lib.slam_batch_sizeof.restype = sz
         if lib.slam_batch_sizeof() != C.sizeof(Batch):
             raise RuntimeError(f"{LIB_PATH}: slam_batch is {lib.slam_batch_sizeof()} bytes in the library, "
                                f"{C.sizeof(Batch)} in this binding -- rebuild the library or update the binding")
-        lib.slam_raster_dev.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, vp]
+        lib.slam_raster_dev.argtypes = [vp, vp, vp, vp, vp, u32, i32, i32, vp, u32]
+        lib.slam_cells_per_frame.argtypes = [i32]
+        lib.slam_cells_per_frame.restype = u32
         lib.slam_synth_text_len.argtypes = [u32, u32]
         lib.slam_synth_text_len.restype = sz
         lib.slam_synth_frames_dev.argtypes = [vp, vp, u64, u32, u32, u32, u32, u64]
@@ -121,7 +130,7 @@ def load() -> C.CDLL:
         lib.slam_timing_read.argtypes = [vp, vp, vp, vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len", "slam_row_tiles"):
+            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len", "slam_row_tiles", "slam_cells_per_frame"):
                 fn.restype = C.c_int
         _lib = lib
         return lib

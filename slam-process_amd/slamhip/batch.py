@@ -28,18 +28,29 @@ def _pack(chunks: Sequence[np.ndarray], device) -> tuple:
     return torch.from_numpy(buf).to(device), offs, lens
 
 
-def _collect(pipe: FramePipeline, n: int) -> List[Dict]:
+def _collect(pipe: FramePipeline, n: int, rows: bool, tiles: str) -> List[Dict]:
     st = pipe.stats_host()
     out = []
     for f in range(n):
         full, bl, aod, aoa, lo, hi = pipe.frame_matrix(f, st)
-        out.append(dict(stats=st[f].copy(), rows=pipe.frame_rows(f, st), kept=pipe.frame_kept(f, st),
-                        matrix=full, blurred=bl, aod=aod, aoa=aoa, vmin=lo, vmax=hi, tile=pipe.frame_tile(f)))
+        r = dict(stats=st[f].copy(), matrix=full, blurred=bl, aod=aod, aoa=aoa, vmin=lo, vmax=hi)
+        if rows:                    # the row arrays are the bulk of a capture's results: fetched only when asked for
+            r.update(rows=pipe.frame_rows(f, st), kept=pipe.frame_kept(f, st))
+        if tiles == "host":
+            r["tile"] = pipe.frame_tile(f)
+        else:                       # a view of the pipeline's tile buffer: stays on the device (e.g. for a gather)
+            r["tile_dev"] = pipe.tiles[f]
+        out.append(r)
     return out
 
 
-def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, **pipeline_kwargs) -> List[Dict]:
-    """Every text through decode -> correct -> pivot -> blur -> raster on the GPU; one dict per text."""
+def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, rows: bool = True, tiles: str = "host",
+                  **pipeline_kwargs) -> List[Dict]:
+    """Every text through decode -> correct -> pivot -> blur -> raster on the GPU; one dict per text: the stats
+    words, the matrices and their axes, the tile ("tile": host array, or with tiles="device" "tile_dev": device
+    tensor), and with rows=True the decoded records and the corrected rows."""
+    if tiles not in ("host", "device"):
+        raise ValueError("tiles must be 'host' or 'device'")
     if not texts:
         return []
     dev = torch.device("cuda", device)
@@ -48,7 +59,7 @@ def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, **p
     pipe = FramePipeline(len(arrs), max(max(lens), 1), device=device, tile_w=tile, tile_h=tile, **pipeline_kwargs)
     pipe.set_layout(offs, lens)
     pipe.run(buf, stages=STAGE_ALL)
-    res = _collect(pipe, len(arrs))
+    res = _collect(pipe, len(arrs), rows, tiles)
     loose = [i for i, r in enumerate(res) if r["stats"][_lib.STAT_NOT_STRICT]]
     if loose:
         data = [ops.hex_unpack(arrs[i], device=device) for i in loose]
@@ -57,16 +68,19 @@ def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, **p
                               src_is_bytes=True, **pipeline_kwargs)
         bpipe.set_layout(boffs, blens)
         bpipe.run(bbuf, stages=STAGE_ALL)
-        for i, r in zip(loose, _collect(bpipe, len(data))):
+        for i, r in zip(loose, _collect(bpipe, len(data), rows, tiles)):
             res[i] = r
     return res
 
 
 def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 1024, gather_via_host: bool = False,
-                          **pipeline_kwargs):
+                          rows: bool = False, timing: Optional[Dict] = None, **pipeline_kwargs):
     """Under torch.distributed: each rank processes the files `balance_files` gives it; rank 0 receives every
     file's tile (list indexed like `paths`), other ranks None.  Without an initialised process group: all files.
-    `gather_via_host` stages the gather through host memory (for a gloo process group)."""
+    `gather_via_host` stages the gather through host memory (for a gloo process group); otherwise the tiles stay
+    on the device from the raster kernel through the gather.  rows=True also fetches every log's decoded and
+    corrected rows.  `timing`, if given, receives this rank's seconds for reading, processing and gathering."""
+    import time
     import os
     import torch.distributed as dist
     from . import dist as D
@@ -75,15 +89,28 @@ def process_files_sharded(paths: Sequence[str], device: int = 0, tile: int = 102
     sizes = [os.path.getsize(p) for p in paths]
     bins = D.balance_files(sizes, world)
     mine = bins[rank]
-    res = process_texts([open(paths[i], "rb").read() for i in mine], device=device, tile=tile, **pipeline_kwargs)
+    t0 = time.perf_counter()
+    texts = [open(paths[i], "rb").read() for i in mine]
+    t1 = time.perf_counter()
+    res = process_texts(texts, device=device, tile=tile, rows=rows, tiles="device", **pipeline_kwargs)
+    torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    if timing is not None:
+        timing.update(read_s=t1 - t0, process_s=t2 - t1, text_bytes=sum(len(t) for t in texts), logs=len(texts))
     if world == 1:
-        return [r["tile"] for r in res], res
+        out1 = [r["tile_dev"].cpu().numpy() for r in res]
+        if timing is not None:
+            timing["gather_s"] = time.perf_counter() - t2
+        return out1, res
     per = max(len(b) for b in bins)
     dev = torch.device("cuda", device)
     tiles = torch.zeros((per, tile, tile, 4), dtype=torch.uint8, device=dev)
     for j, r in enumerate(res):
-        tiles[j] = torch.from_numpy(r["tile"]).to(dev)
+        tiles[j].copy_(r["tile_dev"])               # device to device
     got = D.gather_tiles(tiles.cpu() if gather_via_host else tiles, dst=0)
+    if timing is not None:
+        torch.cuda.synchronize(device)
+        timing["gather_s"] = time.perf_counter() - t2
     if rank != 0:
         return None, res
     out: List[Optional[np.ndarray]] = [None] * len(paths)

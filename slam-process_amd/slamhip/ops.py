@@ -138,22 +138,46 @@ def correct(flag, ue, bs, rss, clk, cycle: int = CYCLE, tol: int = TOL, mod_base
 
 
 def axis_from_mapping(mapping: Dict[int, float]):
-    """BeamID->angle dict -> (beam_to_axis int8[64], sorted distinct angles f64).  Ids outside 0..63 are ignored
+    """BeamID->angle dict -> (beam_to_axis int16[64], sorted distinct angles f64).  Ids outside 0..63 are ignored
     (excel_heatmap_v3.py:246-247)."""
     items = [(int(k), float(a)) for k, a in mapping.items() if 0 <= int(k) <= 63 and not math.isnan(float(a))]
     angles = sorted({a for _, a in items})
     pos = {a: i for i, a in enumerate(angles)}
-    b2a = np.full(64, -1, np.int8)
+    b2a = np.full(64, -1, np.int16)
     for k, a in items:
         b2a[k] = pos[a]
     return b2a, np.array(angles, np.float64)
+
+
+def upscaled_axis(mapping: Dict[int, float], factor: int = 4):
+    """The up-scaled beam table: the mapping's sorted distinct angles interpolated linearly to `factor` times as many
+    entries (entry factor*i is angle i; the entries past the last angle continue its last step), and every beam at
+    entry factor * (its index among the distinct angles).  Returns (beam_to_axis int16[64], angles f64).
+
+    The reference has no such mode (its validate_beam_id admits 64 beams, excel_heatmap_v3.py:68-72): this is the
+    benchmark configuration "4x upscaled beam table", rendered over the full grid (slam_batch.full_grid)."""
+    b2a, angles = axis_from_mapping(mapping)
+    factor = int(factor)
+    if factor < 1 or len(angles) * factor > _lib.MAX_AXIS:
+        raise ValueError(f"up-scaled table of {len(angles)} x {factor} entries exceeds {_lib.MAX_AXIS}")
+    if factor == 1 or len(angles) == 0:
+        return b2a, angles
+    n = len(angles)
+    j = np.arange(n * factor, dtype=np.float64) / factor
+    if n == 1:
+        up = angles[0] + j                      # a lone angle: unit steps, like _edges' +-0.5 around a single value
+    else:
+        i0 = np.minimum(np.floor(j).astype(np.int64), n - 2)
+        up = angles[i0] + (j - i0) * (angles[i0 + 1] - angles[i0])
+    up[::factor] = angles                       # the table's own angles exactly
+    return np.where(b2a >= 0, b2a * factor, -1).astype(np.int16), np.ascontiguousarray(up, np.float64)
 
 
 def pivot_mean(ue, bs, rss, beam_to_axis: np.ndarray, n_axis: int, device: int = 0):
     """map_angles + compute_rssi_matrix's data path: (sum int64, cnt int64, mean f64) on the full axis grid."""
     c = _lib.ctx(device)
     u, b, r = (_i32(x, n) for x, n in ((ue, "ue_beam"), (bs, "bs_beam"), (rss, "rss")))
-    b2a = np.ascontiguousarray(beam_to_axis, dtype=np.int8)
+    b2a = np.ascontiguousarray(beam_to_axis, dtype=np.int16)
     s = np.zeros((n_axis, n_axis), np.int64)
     k = np.zeros((n_axis, n_axis), np.int64)
     m = np.empty((n_axis, n_axis), np.float64)

@@ -42,22 +42,30 @@ class FramePipeline:
                  blur_sigma: float = 1.0, use_log: bool = False, vmin: Optional[float] = None,
                  vmax: Optional[float] = None, cycle: int = ops.CYCLE, tol: int = ops.TOL,
                  mod_base: int = ops.MOD_BASE, src_is_bytes: bool = False, n_tile_slots: Optional[int] = None,
-                 n_compact_slots: int = 1, reserve: bool = True):
+                 n_compact_slots: int = 1, reserve: bool = True, upscale: int = 1,
+                 full_grid: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("FramePipeline needs a GPU (the HIP path has no CPU fallback)")
         self.dev = torch.device("cuda", device)
-        self.ctx = _lib.ctx(device)
+        # A ctx of its own: the library workspace this pipeline reserves is never re-pointed by other callers of the
+        # process-wide ctx (ops.*, other pipelines), so graphs captured from run() stay valid as long as it lives.
+        self.ctx = _lib.Context(device)
         self.F = int(max_frames)
         self.max_text_len = int(max_text_len)
         self.row_tiles = int(self.ctx.lib.slam_row_tiles(self.max_text_len, 1 if src_is_bytes else 0))
         self.row_cap = ((self.row_tiles * _lib.TILE_SLOTS + 15) // 16) * 16
         self.tile_w, self.tile_h = int(tile_w), int(tile_h)
-        b2a, angles = ops.axis_from_mapping(mapping if mapping is not None else default_mapping())
+        # upscale > 1: the beam table interpolated to `upscale` times as many entries and the full grid rendered
+        # (ops.upscaled_axis); 1: the reference's semantics, rows and columns are the angles that occur
+        self.upscale = int(upscale)
+        self.full_grid = (self.upscale > 1) if full_grid is None else bool(full_grid)
+        b2a, angles = ops.upscaled_axis(mapping if mapping is not None else default_mapping(), self.upscale)
         self.n_axis = len(angles)
+        self.cells_per_frame = _lib.cells_per_frame(self.n_axis)
         self.axis_angles = angles
         F, rc, d = self.F, self.row_cap, self.dev
         u8, u32 = torch.uint8, torch.int32
-        self.b2a = torch.from_numpy(b2a.view(np.uint8).copy()).to(d)
+        self.b2a = torch.from_numpy(b2a.astype(np.int16)).to(d)
         self.angles = torch.from_numpy(angles.copy()).to(d)
         self.lut = torch.from_numpy(np.ascontiguousarray(lut if lut is not None else viridis_lut(), np.uint8).copy()).to(d)
         self.flag = torch.empty(F * rc, dtype=u8, device=d)
@@ -74,7 +82,7 @@ class FramePipeline:
         self.k_clk = torch.empty(F * rc, dtype=u32, device=d)
         # What a tile is painted from (cell colours, pixel -> cell maps) and the frame's stats words live in one
         # flat buffer per slot, so a rank can ship a batch's results in one 20 KB-per-frame message.
-        self.compact_layout = compact_layout(F, self.tile_w, self.tile_h)
+        self.compact_layout = compact_layout(F, self.tile_w, self.tile_h, self.cells_per_frame)
         self.compact = torch.zeros((int(n_compact_slots), self.compact_layout["bytes"]), dtype=u8, device=d)
         self.compact_slot = 0
         self.matrix = torch.empty(F * self.n_axis * self.n_axis, dtype=torch.float64, device=d)
@@ -92,6 +100,7 @@ class FramePipeline:
         bt.beam_to_axis_dev = self.b2a.data_ptr()
         bt.axis_angle_dev = self.angles.data_ptr()
         bt.n_axis = self.n_axis
+        bt.full_grid = 1 if self.full_grid else 0
         bt.blur_sigma = float(blur_sigma)
         bt.use_log = 1 if use_log else 0
         bt.vmin = nan if vmin is None else float(vmin)
@@ -203,8 +212,11 @@ class FramePipeline:
         full = self.matrix[f * na * na:(f + 1) * na * na].cpu().numpy().reshape(na, na)
         h, w = int(st[f, _lib.STAT_N_AOD]), int(st[f, _lib.STAT_N_AOA])
         bl = self.blurred[f * na * na: f * na * na + h * w].cpu().numpy().reshape(h, w)
-        cnt_rows = np.flatnonzero(np.isfinite(full).any(axis=1))
-        cnt_cols = np.flatnonzero(np.isfinite(full).any(axis=0))
+        if self.full_grid:            # every entry of the axis table is a row and a column
+            cnt_rows = cnt_cols = np.arange(na)
+        else:
+            cnt_rows = np.flatnonzero(np.isfinite(full).any(axis=1))
+            cnt_cols = np.flatnonzero(np.isfinite(full).any(axis=0))
         vv = st[f, _lib.STAT_VMIN_LO:_lib.STAT_VMAX_HI + 1].copy().view(np.float64)
         return full, bl, self.axis_angles[cnt_rows], self.axis_angles[cnt_cols], float(vv[0]), float(vv[1])
 
@@ -213,30 +225,31 @@ class FramePipeline:
         return self.tiles[tile_slot + f].cpu().numpy()
 
 
-def compact_layout(F: int, W: int, H: int) -> Dict[str, int]:
-    """Byte offsets of the per-batch result buffer: cells [F*16384] | colmap [F*2W] | rowmap [F*2H] | stats [F*64]."""
+def compact_layout(F: int, W: int, H: int, cells_per_frame: int = 4096) -> Dict[str, int]:
+    """Byte offsets of the per-batch result buffer: cells [F*cells_per_frame*4] | colmap [F*2W] | rowmap [F*2H] |
+    stats [F*64]."""
     al = lambda x: (x + 255) // 256 * 256
     cells = 0
-    colmap = al(cells + F * 4096 * 4)
+    colmap = al(cells + F * cells_per_frame * 4)
     rowmap = al(colmap + F * W * 2)
     stats = al(rowmap + F * H * 2)
     return dict(cells=cells, colmap=colmap, rowmap=rowmap, stats=stats, bytes=al(stats + F * _lib.STAT_WORDS * 4))
 
 
 def expand_compact(buf: torch.Tensor, F: int, W: int, H: int, out: Optional[torch.Tensor] = None,
-                   device: Optional[int] = None) -> torch.Tensor:
+                   device: Optional[int] = None, cells_per_frame: int = 4096) -> torch.Tensor:
     """Paint the F tiles a compact result buffer (FramePipeline.compact[slot], possibly received from another rank)
     describes: [F, H, W, 4] uint8, bit-identical to the tiles the producing pipeline rendered."""
     dev = buf.device
     c = _lib.ctx(dev.index if device is None else device)
-    lay = compact_layout(F, W, H)
+    lay = compact_layout(F, W, H, cells_per_frame)
     if out is None:
         out = torch.empty((F, H, W, 4), dtype=torch.uint8, device=dev)
     c.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     base = buf.data_ptr()
     c.check(c.lib.slam_raster_dev(c.h, C.c_void_p(base + lay["cells"]), C.c_void_p(base + lay["colmap"]),
                                   C.c_void_p(base + lay["rowmap"]), C.c_void_p(base + lay["stats"]), int(F), int(W),
-                                  int(H), C.c_void_p(out.data_ptr())))
+                                  int(H), C.c_void_p(out.data_ptr()), int(cells_per_frame)))
     return out
 
 

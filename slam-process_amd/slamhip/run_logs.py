@@ -53,7 +53,9 @@ def main(argv=None) -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
-    tiles, res = batch.process_files_sharded(paths, device=local, tile=a.tile, gather_via_host=a.backend == "gloo")
+    timing = {}
+    tiles, res = batch.process_files_sharded(paths, device=local, tile=a.tile, gather_via_host=a.backend == "gloo",
+                                             timing=timing)
     # every rank reports its own logs' counters; rank 0 also writes the gathered tiles
     from . import dist as D
     mine = D.balance_files([os.path.getsize(p) for p in paths], world)[rank]
@@ -64,6 +66,16 @@ def main(argv=None) -> int:
                                kept=int(st[_lib.STAT_KEPT]), grid=[len(r["aod"]), len(r["aoa"])]), ensure_ascii=False)
         sys.stdout.write(line + "\n")          # one write per line: the ranks share the launcher's pipe
         sys.stdout.flush()
+    # throughput of this rank's share: logs and text bytes per second through the device chain (file reading and the
+    # gather are reported beside it, not inside it)
+    proc = max(timing.get("process_s", 0.0), 1e-9)
+    sys.stdout.write(json.dumps(dict(summary=True, rank=rank, world=world, logs=timing.get("logs", 0),
+                                     text_MB=round(timing.get("text_bytes", 0) / 1e6, 3),
+                                     logs_per_s=round(timing.get("logs", 0) / proc, 2),
+                                     text_MB_per_s=round(timing.get("text_bytes", 0) / 1e6 / proc, 1),
+                                     read_s=round(timing.get("read_s", 0.0), 4), process_s=round(proc, 4),
+                                     gather_s=round(timing.get("gather_s", 0.0), 4))) + "\n")
+    sys.stdout.flush()
     if rank == 0:
         for p, t in zip(paths, tiles):
             d = a.out_dir or os.path.join(os.path.dirname(os.path.abspath(p)), "heatmap_outputs")

@@ -1079,3 +1079,290 @@ def test_batched_correction_long_groups_with_few_baselines(mapping, lut, n_basel
     kept = pipe.frame_kept(0, st)
     for k in kept_o:
         assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), k
+
+
+# ---- the up-scaled beam table (axis tables of up to 256 entries, full grid) ---------------------------------------
+# Parity unpinned on the reference, which admits 64 beams only (excel_heatmap_v3.py:68-72): these hold the HIP path
+# to the oracle's restatement of the build's own definition (O.upscaled_axis), and to the 64-entry results where
+# the two must coincide.
+@pytest.mark.parametrize("factor", [2, 3, 4])
+def test_wide_axis_host_entry_points_match_oracle(ops, mapping, lut, factor):
+    z = np.load(os.path.join(GOLDEN, "log0.npz"))
+    k = z["kept"]
+    b2a, angles = ops.upscaled_axis(mapping, factor)
+    ob2a, oangles = O.upscaled_axis(mapping, factor)
+    assert np.array_equal(b2a, ob2a) and np.array_equal(angles, oangles) and len(angles) == 64 * factor
+    s, c, m = ops.pivot_mean(k[:, 0], k[:, 1], k[:, 2], b2a, len(angles))
+    mat, aod, aoa, so, co = O.pivot_mean(k[:, 0], k[:, 1], k[:, 2], mapping, upscale=factor)
+    assert np.array_equal(s, so) and np.array_equal(c, co) and int(c.sum()) == len(k)
+    assert np.array_equal(m, mat, equal_nan=True) and mat.shape == (64 * factor, 64 * factor)
+    bl = ops.blur_nan(mat, 1.0)
+    ob = O.blur_nan_aware(mat, 1.0)
+    assert np.array_equal(np.isnan(bl), np.isnan(ob))
+    fin = np.isfinite(ob)
+    assert fin.any() and np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL
+    for use_log in (False, True):
+        cells, tile, lo, hi = ops.render(bl, aod, aoa, lut, use_log=use_log, W=300, H=200)
+        r = O.render(bl, aod, aoa, lut, use_log=use_log, blur_sigma=0.0, W=300, H=200)
+        assert (lo, hi) == (r["vmin"], r["vmax"])
+        if use_log:
+            d = np.abs(tile.astype(int) - r["tile"].astype(int))
+            assert (d.max(axis=2) > 0).mean() <= 0.01 and d.max() <= 3
+        else:
+            assert np.array_equal(cells, r["cells"]) and np.array_equal(tile, r["tile"])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(use_log=True), dict(blur_sigma=0.0), dict(blur_sigma=2.0),
+                                  dict(upscale=2), dict(upscale=3), dict(sparse=True), dict(sparse=True, upscale=2)])
+def test_batched_pipeline_upscaled_table(mapping, lut, opts):
+    """The batched call with the up-scaled table (full grid of up to 256 x 256 cells) against the oracle."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, expand_compact, synth_frames
+    o = dict(opts)
+    up = o.pop("upscale", 4)
+    mp = {i: float(i // 2) for i in range(0, 64) if i % 7} if o.pop("sparse", False) else mapping   # duplicates, holes
+    B, N, F, W, H = 8, 1024, 2, 320, 200
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=123)
+    pipe = FramePipeline(F, tl, tile_w=W, tile_h=H, mapping=mp, lut=lut, upscale=up, **o)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    st = pipe.stats_host()
+    sigma = o.get("blur_sigma", 1.0)
+    n_axis = len(O.upscaled_axis(mp, up)[1])
+    assert pipe.n_axis == n_axis
+    for f in range(F):
+        kept = pipe.frame_kept(f, st)
+        mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mp, upscale=up)
+        full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
+        assert (int(st[f, 7]), int(st[f, 8])) == (n_axis, n_axis) and int(st[f, 9]) == 0
+        assert np.array_equal(aod_g, aod) and np.array_equal(aoa_g, aoa)
+        assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+        ob = O.blur_nan_aware(mat, sigma)
+        assert np.array_equal(np.isnan(bl), np.isnan(ob))
+        fin = np.isfinite(ob)
+        assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL
+        r = O.render(bl, aod, aoa, lut, use_log=o.get("use_log", False), blur_sigma=0.0, W=W, H=H)
+        assert (lo, hi) == (r["vmin"], r["vmax"])
+        tile = pipe.frame_tile(f)
+        if o.get("use_log"):
+            d = np.abs(tile.astype(int) - r["tile"].astype(int))
+            assert (d.max(axis=2) > 0).mean() <= 0.01 and d.max() <= 3
+        else:
+            assert np.array_equal(tile, r["tile"])
+    again = expand_compact(pipe.compact[pipe.compact_slot].clone(), F, W, H, cells_per_frame=pipe.cells_per_frame)
+    assert torch.equal(again, pipe.tiles[:F])
+
+
+def test_wide_axis_without_the_full_grid_equals_the_64_entry_table(mapping, lut):
+    """With the up-scaled table but the reference's axis rule (rows and columns are the angles that occur), only the
+    table's own 64 angles can occur: matrix, blur and tile must be those of the 64-entry table, bit for bit."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 16, 1024, 3
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=9)
+    res = []
+    for up, fg in ((1, None), (4, False)):
+        pipe = FramePipeline(F, tl, tile_w=200, tile_h=120, mapping=mapping, lut=lut, upscale=up, full_grid=fg)
+        pipe.set_uniform_layout(F, stride, tl)
+        pipe.run(text)
+        st = pipe.stats_host()
+        res.append((st.copy(), [pipe.frame_matrix(f, st) for f in range(F)], pipe.tiles[:F].clone()))
+    (st1, m1, t1), (st4, m4, t4) = res
+    assert np.array_equal(st1, st4) and torch.equal(t1, t4)
+    for a, b in zip(m1, m4):
+        assert np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))          # blurred, bit for bit
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4:] == b[4:]
+        assert np.array_equal(a[0], b[0][::4, ::4], equal_nan=True) and np.isnan(b[0][1::4]).all()
+
+
+def test_blur_of_a_large_matrix_runs_over_the_whole_chip(ops):
+    """slam_blur_nan on a 1500 x 1100 matrix with a 19-tap kernel: one cell per thread over a grid, seconds not minutes."""
+    import time
+    rng = np.random.default_rng(5)
+    m = rng.uniform(-50, 50, (1500, 1100))
+    m[rng.random(m.shape) < 0.3] = np.nan
+    t0 = time.perf_counter()
+    got = ops.blur_nan(m, 3.0)
+    dt = time.perf_counter() - t0
+    exp = O.blur_nan_aware(m, 3.0)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    fin = np.isfinite(exp)
+    assert np.max(np.abs(got[fin] - exp[fin]) / np.maximum(np.abs(exp[fin]), 1e-9)) <= 1e-10
+    assert dt < 20.0
+
+
+@pytest.mark.parametrize("cycle,tol,mod_base", [(61000, 500, 10), (61000, 500, 255), (61000, 500, 1), (61000, 500, 128),
+                                                (1000, 700, 10), (1000, 500, 255), (64, 31, 100), (977, 0, 3)])
+def test_batched_correction_with_other_moduli(mapping, lut, cycle, tol, mod_base):
+    """(bs_b + k) % MOD_BASE is Python's modulo for any positive MOD_BASE (bs_beam_correction.py:158): moduli that are
+    not powers of two leave the masked fast path, with small tables (registers), tables of 100 and 300 phases (LDS) and
+    tolerances of half a cycle and more; the batched correction against the oracle with the same constants."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    streams = [_wrap_stream(cycle, 31), _wrap_stream(cycle, 32, groups=2, rows_per_group=400, n_baselines=100),
+               _wrap_stream(cycle, 33, groups=2, rows_per_group=1000, n_baselines=300),
+               _wrap_stream(cycle, 34, groups=300, rows_per_group=3, n_baselines=1)]
+    offs, lens, blob = [], [], bytearray()
+    for sbytes in streams:
+        while len(blob) % 16:
+            blob.append(0xEE)
+        offs.append(len(blob)); lens.append(len(sbytes)); blob += sbytes
+    blob += b"\xEE" * 64
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(streams), max(lens), tile_w=64, tile_h=64, mapping=mapping, lut=lut, src_is_bytes=True,
+                         cycle=cycle, tol=tol, mod_base=mod_base)
+    pipe.set_layout(offs, lens)
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    st = pipe.stats_host()
+    for f, sbytes in enumerate(streams):
+        rows_o, v, d = O.parse_groups(np.frombuffer(sbytes, np.uint8))
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"],
+                                            cycle=cycle, tol=tol, mod_base=mod_base)
+        assert (int(st[f, 2]), int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (v, ng, nb, len(kept_o["ue"])), f
+        assert len(kept_o["ue"]) > 50 and int(kept_o["bs"].max()) < mod_base
+        kept = pipe.frame_kept(f, st)
+        for k in kept_o:
+            assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (f, k)
+
+
+def test_loose_text_frames_come_back_empty(mapping, lut):
+    """A frame whose text is not in the strict capture format is flagged and comes back with no rows at all -- counters
+    zero, no entries to walk, blank tile -- wherever in the text the stray character sits, and its neighbours in the
+    batch are untouched."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline
+    B, N = 16, 1024
+    good = [synth.make_frame_text(B, N, k) for k in (3, 4)]
+    tl = len(good[0])
+    bad = []
+    for pos, ch in ((tl // 2, ord("G")), (tl - 2, ord("x")), (7, 0x0A), (tl // 3 + 2, ord("-")), (3 * 5000 + 3 + 1, 0xC3)):
+        t = good[0].copy()
+        t[pos] = ch
+        bad.append(t)
+    bad.append(good[0][:-2].copy())                                    # a dangling digit at the end
+    frames = [good[0], bad[0], bad[1], good[1], bad[2], bad[3], bad[4], bad[5]]
+    offs, lens, blob = [], [], bytearray()
+    for t in frames:
+        while len(blob) % 256:
+            blob.append(0x20)
+        offs.append(len(blob)); lens.append(len(t)); blob += t.tobytes()
+    blob += b" " * 256
+    text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+    pipe = FramePipeline(len(frames), tl, tile_w=64, tile_h=48, mapping=mapping, lut=lut)
+    pipe.set_layout(offs, lens)
+    pipe.tiles.fill_(9)
+    pipe.run(text)
+    st = pipe.stats_host()
+    want = {}
+    for f, k in ((0, 3), (3, 4)):
+        rows_o, v, d = O.parse_groups(synth.make_frame_bytes(B, N, k))
+        kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
+        assert [int(x) for x in st[f, 1:7]] == [0, v, d, ng, nb, len(kept_o["ue"])]
+        kept = pipe.frame_kept(f, st)
+        for c in kept_o:
+            assert np.array_equal(kept[c].astype(np.int64), kept_o[c]), (f, c)
+        assert pipe.frame_tile(f)[..., 3].all()
+    for f in (1, 2, 4, 5, 6, 7):
+        assert int(st[f, 1]) == 1, f
+        assert [int(x) for x in st[f, 2:9]] == [0, 0, 0, 0, 0, 0, 0], (f, st[f])          # valid .. kept, grid 0 x 0
+        assert int(st[f, 9]) == 1 and int(st[f, 14]) == 0, f
+        assert len(pipe.frame_rows(f, st)["flag"]) == 0 and len(pipe.frame_kept(f, st)["ue"]) == 0
+        tile = pipe.frame_tile(f)
+        assert not tile[..., 3].any() and (tile[..., :3] == 255).all(), f
+
+
+def test_render_stage_again_after_a_failed_one(mapping, lut):
+    """Stage 4 on its own, first with log-scale limits the reference's LogNorm rejects (status 2, blank tiles), then
+    with valid ones on the same stats words: the second render's tiles are those of a fresh run, the status cleared."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT, STAGE_RENDER, synth_frames
+    B, N, F = 8, 512, 2
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=70)
+    ref = FramePipeline(F, tl, tile_w=96, tile_h=64, mapping=mapping, lut=lut, use_log=True)
+    ref.set_uniform_layout(F, stride, tl)
+    ref.run(text)
+    st_ref = ref.stats_host().copy()
+    assert (st_ref[:, 9] == 0).all()
+    pipe = FramePipeline(F, tl, tile_w=96, tile_h=64, mapping=mapping, lut=lut, use_log=True, vmin=10.0, vmax=30000.0)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+    pipe.run(text, stages=STAGE_RENDER)
+    st = pipe.stats_host()
+    assert (st[:, 9] == 2).all() and not pipe.tiles[:F, ..., 3].any()
+    pipe.bt.vmin = pipe.bt.vmax = float("nan")
+    pipe.run(text, stages=STAGE_RENDER)
+    st = pipe.stats_host()
+    assert np.array_equal(st, st_ref)
+    assert torch.equal(pipe.tiles[:F], ref.tiles[:F])
+
+
+def test_workspace_cannot_move_under_a_captured_graph(mapping, lut):
+    """A pipeline's graph stays valid whatever other callers do (it has a ctx of its own); a call that would have to
+    grow the workspace, or re-upload blur weights, while its stream is being captured fails instead of allocating; a
+    pinned ctx refuses to grow after the capture as well."""
+    import ctypes as C
+    import torch
+    from slamhip import _lib, ops, synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 16, 1024, 2
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=5)
+    pipe = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    torch.cuda.synchronize()
+    want = (pipe.tiles.clone(), pipe.stats.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.run(text)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    errors = []
+    with torch.cuda.graph(g, stream=side):
+        pipe.run(text)
+        # while capturing: another blur sigma would re-upload the weights, a larger batch would grow the workspace
+        for field, value in (("blur_sigma", 2.0), ("max_text_len", 8 * tl)):
+            old = getattr(pipe.bt, field)
+            setattr(pipe.bt, field, value)
+            if field == "max_text_len":
+                pipe.bt.row_cap = 8 * pipe.row_cap
+            rc = pipe.ctx.lib.slam_process_frames_dev(pipe.ctx.h, C.byref(pipe.bt), 7)
+            errors.append((field, rc, pipe.ctx.lib.slam_last_error(pipe.ctx.h).decode()))
+            setattr(pipe.bt, field, old)
+            pipe.bt.row_cap = pipe.row_cap
+    assert [(f, rc) for f, rc, _ in errors] == [("blur_sigma", _lib.E_INVALID), ("max_text_len", _lib.E_INVALID)], errors
+    # other callers of the library (the process-wide ctx) grow their own workspace, not this pipeline's
+    big = np.frombuffer(synth.make_frame_text(64, 2048, 1).tobytes(), np.uint8)
+    assert len(ops.hex_unpack(big)) == len(synth.make_frame_bytes(64, 2048, 1))
+    other = FramePipeline(4 * F, 4 * tl, tile_w=64, tile_h=64, mapping=mapping, lut=lut)
+    del other
+    pipe.tiles.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.tiles, want[0]) and torch.equal(pipe.stats, want[1])
+    # pinned: a host-pointer call on the pipeline's own ctx that needs more workspace is refused, the graph still replays
+    pipe.ctx.check(pipe.ctx.lib.slam_pin_workspace(pipe.ctx.h, 1))
+    huge = np.zeros(1 << 28, np.uint8)
+    out = np.empty(len(huge) // 2 + 2, np.uint8)
+    n = C.c_size_t(0)
+    rc = pipe.ctx.lib.slam_hex_unpack(pipe.ctx.h, huge.ctypes.data_as(C.c_void_p), len(huge), out.ctypes.data_as(C.c_void_p),
+                                      len(out), C.byref(n))
+    assert rc == _lib.E_CAPACITY
+    pipe.tiles.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.tiles, want[0]) and torch.equal(pipe.stats, want[1])
+    pipe.ctx.check(pipe.ctx.lib.slam_pin_workspace(pipe.ctx.h, 0))
