@@ -11,6 +11,7 @@ over RCCL on a side stream while the next step computes.  --gather compact (defa
 is painted from (cell colours + pixel->cell maps + stats, 20.6 KB per 4 MiB tile; slam_raster_dev repaints it
 bit for bit on the receiver, checked after the timed region against one full-tile gather); --gather tiles
 ships the 4 MiB tiles themselves, which at this frame rate is bound by rank 0's xGMI ingest, not by compute.
+With N > 1 the other gather mode is timed too, after the headline region, and both rates are reported.
 
 Rank 0 prints ONE JSON line.  `value` is frames/s over all ranks with the text already in HBM when
 the clock starts.  `roofline` prices the dominant kernel (algorithmic bytes / its mean duration from
@@ -19,6 +20,8 @@ HIP events on the launch stream) against the 8 TB/s HBM peak; `cpu_baseline` is 
 single-threaded worker process per host core of the box's share (16).  Two checks ride along after the clock:
 `cpu_baseline.parity_check` holds the device's results for frame 0 against that oracle's for the same frame, and
 `roofline.measured_ceilings` gives what plain read, copy and 3:1 read/write streams reach on the same device.
+At N = 1, `other_configs` carries short passes over the two other synthetic shapes the benchmark is specified for
+(256 x 16384 long sweeps; 1024 x 8192 with the 4x up-scaled beam table), run after the headline region.
 """
 from __future__ import annotations
 
@@ -48,12 +51,14 @@ def parse_args():
     p.add_argument("--beams", type=int, default=256, help="rows (UE sweeps) per frame")
     p.add_argument("--samples", type=int, default=4096, help="records per row")
     p.add_argument("--tile", type=int, default=1024)
+    p.add_argument("--upscale", type=int, default=1, help="beam table up-scaled by this factor, full grid rendered")
     p.add_argument("--distinct-frames", type=int, default=1600, help="frames kept resident in HBM (ring)")
     p.add_argument("--gather", choices=("compact", "tiles", "none"), default="compact",
                    help="N>1: what every step sends to rank 0")
     p.add_argument("--no-gather", action="store_true", help="same as --gather none")
     p.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short passes over the other shapes")
     p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                    help="N>1 process group; gloo (collectives staged through host memory) only to rehearse the "
                         "multi-rank control flow on a box with fewer GPUs than ranks")
@@ -146,11 +151,279 @@ def measured_ceilings(ctx, pipe, achieved_gbs):
                 probe_bytes=n, frac_of_read3_write1=round(achieved_gbs / mix, 4))
 
 
+# The two builds of the fused correction kernel share one job: frames (or workgroups) the lean build leaves go to the
+# full one, so their times add up against one set of algorithmic bytes.
+KERNEL_GROUPS = {"rows_finish": ("rows_finish", "rows_finish_rest")}
+
+
+def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_of, B, N, upscale):
+    """Per-kernel table and the roofline entry of the dominant kernel.  `kern`: name -> (launches, total ms) from the
+    library's HIP-event timers.  Algorithmic bytes per frame (each kernel's own inputs and outputs once, re-reads not
+    counted); kernels that split one job (KERNEL_GROUPS) are priced together."""
+    alg = {
+        "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
+        "tile_groups": 0.5 * valid,                      # 12 bits per 4 entries
+        "rows_finish": 10.0 * valid + 10.0 * kept,       # flag, ue, rss, clk in; kept rows out
+        "pivot": 6.0 * kept,
+        "raster": float(tile_bytes),
+    }
+    merged = {}
+    for name, (launches, ms) in kern.items():
+        group = next((g for g, members in KERNEL_GROUPS.items() if name in members), name)
+        e = merged.setdefault(group, dict(launches=0, ms=0.0, parts={}))
+        e["ms"] += ms
+        e["launches"] = max(e["launches"], launches)      # members are launched once per batch each
+        e["parts"][name] = (launches, ms)
+    tot_ms = sum(e["ms"] for e in merged.values())
+    table = {}
+    for name, e in sorted(merged.items(), key=lambda kv: -kv[1]["ms"]):
+        per = e["ms"] / max(e["launches"], 1)
+        ent = dict(launches=e["launches"], avg_ms=round(per, 5), share=round(e["ms"] / tot_ms, 4))
+        if len(e["parts"]) > 1:
+            ent["parts_avg_ms"] = {k: round(ms / max(l, 1), 5) for k, (l, ms) in e["parts"].items()}
+        if name in alg:
+            gbps = alg[name] * frames_per_launch_of(e["launches"]) / (per * 1e-3) / 1e9
+            if gbps <= HBM_PEAK_GBS:
+                ent["alg_GBps"] = round(gbps, 1)
+            else:                  # a share of the job ran elsewhere or the launch did next to nothing: no figure
+                ent["alg_GBps"] = None
+                ent["alg_note"] = "launch too short for its nominal bytes (work done by another kernel)"
+        table[name] = ent
+    dom = max((n for n in merged if n in alg), key=lambda n: merged[n]["ms"])
+    per = merged[dom]["ms"] / merged[dom]["launches"]
+    fpl = frames_per_launch_of(merged[dom]["launches"])
+    ach = alg[dom] * fpl / (per * 1e-3) / 1e9
+    traffic, note = None, None
+    tag = f"{B}x{N}" + (f"_up{upscale}" if upscale > 1 else "")
+    cands = [os.path.join(ROOT, "profiles", f"r2_pmc_traffic_{tag}.json"), os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")]
+    for pmc in cands:
+        if not os.path.exists(pmc):
+            continue
+        pj = json.load(open(pmc))                 # HBM bytes per launch from committed rocprofv3 PMC passes of this shape
+        parts = [k for k in KERNEL_GROUPS.get(dom, (dom,)) if k in pj["kernels"]]
+        if pj.get("shape") == [B, N] and pj.get("upscale", 1) == upscale and parts:
+            traffic = int(sum(pj["kernels"][k]["fetch_bytes_per_frame"] + pj["kernels"][k]["write_bytes_per_frame"]
+                              for k in parts) * fpl)
+            note = os.path.relpath(pmc, ROOT)
+            break
+    if traffic is None:
+        note = f"no committed PMC pass for shape {tag}"
+    roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=note,
+                alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
+    return table, roof, ach
+
+
+class Job:
+    """Distributed plumbing shared by every measurement of one process."""
+
+    def __init__(self, a):
+        self.a = a
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local = local % max(1, torch.cuda.device_count())          # ranks share GPUs only in a --backend gloo rehearsal
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        self.ranks_seen, self.comm_version = 1, None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+                try:
+                    self.comm_version = "rccl/nccl " + ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception as e:               # noqa: BLE001
+                    self.comm_version = f"nccl (version unavailable: {e})"
+            else:
+                dist.init_process_group("gloo")
+                self.comm_version = "gloo (host-staged rehearsal)"
+            ones = torch.ones(1, dtype=torch.int64, device=self.dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(ones)                      # every rank the process group really holds adds one
+            self.ranks_seen = int(ones.item())
+
+    def gather_to_root(self, src, out_list):
+        """dist.gather of a device tensor to rank 0 (RCCL; through host memory under gloo)."""
+        if self.a.backend == "nccl":
+            self.dist.gather(src, out_list if self.rank == 0 else None, dst=0)
+            return
+        host = src.cpu()
+        tmp = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(host, tmp, dst=0)
+        if self.rank == 0:
+            for o, t in zip(out_list, tmp):
+                o.copy_(t)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def reduce_scalar(self, v, op):
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.a.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+
+def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, extra_modes=()):
+    """W warm-up steps, then K timed steps of F frames of shape B x N on every rank (barrier + synchronize on both
+    sides, max over ranks).  Returns the result dict plus the live objects the follow-up checks need."""
+    from slamhip import _lib, synth
+    from slamhip.pipeline import FramePipeline, default_mapping, expand_compact, synth_frames, viridis_lut
+    a, dev, rank, world = job.a, job.dev, job.rank, job.world
+    mapping, lut = default_mapping(), viridis_lut()
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    n_distinct = max(F, min(n_distinct_want, (K + W) * F))
+    n_distinct = (n_distinct // F) * F
+    modes = [gmode] + [m for m in extra_modes if m != gmode]
+    tiles_mode = world > 1 and "tiles" in modes
+    # fit the batch to the memory that is free: text ring + per frame about 2.5 x its text (row arrays, kept rows,
+    # library workspace; 89 MB measured for a 34.6 MB frame) + its tile slots + the wide grids of an up-scaled table
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    n_axis = 64 * upscale
+    wide = (n_axis * n_axis * (8 + 4 + 4 + 8 + 8 + 8 + 8) if n_axis > 64 else 0)
+    per_frame = 2.5 * stride + tile * tile * 4 * (2 if tiles_mode else 1) + wide + (1 << 20)
+    need = n_distinct * stride + F * per_frame
+    if need > 0.92 * free_b:
+        scale = 0.92 * free_b / need
+        F = max(8, int(F * scale) // 8 * 8)
+        n_distinct = min(n_distinct, 2 * F) // F * F
+        print(f"bench: {free_b / 2**30:.0f} GiB free, batch reduced to {F} frames/step ({n_distinct} resident)", file=sys.stderr)
+    if world > 1:                                            # every rank runs the same batch size
+        Fm = int(job.reduce_scalar(float(F), job.dist.ReduceOp.MIN))
+        if Fm != F:
+            F = Fm
+            n_distinct = min(n_distinct, 2 * F) // F * F
+    # frames of this rank: ids rank*n_distinct .. so every rank works on different data
+    text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=job.local)
+    any_gather = any(m != "none" for m in modes)
+    pipe = FramePipeline(F, tl, device=job.local, tile_w=tile, tile_h=tile, mapping=mapping, lut=lut, upscale=upscale,
+                         n_tile_slots=2 * F if tiles_mode else F, n_compact_slots=2 if any_gather else 1)
+    pipe.set_uniform_layout(F, stride, tl)
+    ctx = pipe.ctx
+    torch.cuda.synchronize(dev)
+    comm_stream = torch.cuda.Stream(dev) if any_gather else None
+
+    def run_mode(mode, with_timing):
+        gather = mode != "none"
+        recv = None
+        if gather and rank == 0:
+            if mode == "tiles":
+                recv = [torch.empty((F, tile, tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)]
+            else:
+                recv = [torch.empty_like(pipe.compact[0]) for _ in range(world)]
+        pending = []
+
+        def step(i):
+            batch = (i * F) % n_distinct
+            slot = (i % 2) * F if mode == "tiles" else 0
+            cslot = i % 2 if gather else 0
+            pipe.run(text, text_base_offset=batch * stride, tile_slot=slot, compact_slot=cslot)
+            if gather:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ev)
+                    src = pipe.tiles[slot:slot + F] if mode == "tiles" else pipe.compact[cslot]
+                    job.gather_to_root(src, recv)
+                    done = torch.cuda.Event()
+                    done.record(comm_stream)
+                # the slot is reused two steps later: compute must wait for this gather
+                pending.append(done)
+                if len(pending) >= 2:
+                    torch.cuda.current_stream(dev).wait_event(pending.pop(0))
+
+        for i in range(W):
+            step(i)
+        torch.cuda.synchronize(dev)
+        if with_timing:
+            ctx.timing_reset()
+            ctx.timing(True)
+        job.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(W + i)
+        torch.cuda.synchronize(dev)
+        job.barrier()
+        t1 = time.perf_counter()
+        kern = {}
+        if with_timing:
+            ctx.timing(False)
+            kern = ctx.timing_read()
+        dt = t1 - t0
+        verified = None
+        if mode == "compact":
+            # after the clock: the last batch's full tiles of every rank travel once, and rank 0 repaints the compact
+            # results it received for that batch; both must be the same bytes
+            full = [torch.empty((F, tile, tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            job.gather_to_root(pipe.tiles[:F], full)
+            if rank == 0:
+                verified = all(bool(torch.equal(expand_compact(recv[r], F, tile, tile, cells_per_frame=pipe.cells_per_frame),
+                                                full[r])) for r in range(world))
+                del full
+        if world > 1:
+            dt = job.reduce_scalar(dt, job.dist.ReduceOp.MAX)
+        del recv
+        return dt, kern, verified
+
+    dt, kern, verified = run_mode(gmode, timing)
+    gather_rates = {gmode: dict(frames_per_s=round(K * F * world / dt, 2), ms_per_step=round(dt / K * 1e3, 4),
+                                gather_verified=verified)}
+    for m in modes[1:]:                                      # the other gather mode(s), after the headline's clock
+        dt2, _k, ver2 = run_mode(m, False)
+        gather_rates[m] = dict(frames_per_s=round(K * F * world / dt2, 2), ms_per_step=round(dt2 / K * 1e3, 4),
+                               gather_verified=ver2)
+
+    # per-frame counts of the last batch for the byte accounting
+    st = pipe.stats_host().astype(np.int64)
+    nbytes = float(st[:, _lib.STAT_NBYTES].mean())
+    valid = float(st[:, _lib.STAT_VALID].mean())
+    kept = float(st[:, _lib.STAT_KEPT].mean())
+    assert int(st[:, _lib.STAT_NOT_STRICT].sum()) == 0
+    kappa = kept / max(valid, 1.0)
+    tile_bytes = tile * tile * 4
+    # algorithmic bytes per frame: read the text (3 per data byte), write decoded records (11 each),
+    # write kept rows (10 each), write the tile
+    alg_frame = 3.0 * nbytes + 11.0 * valid + 10.0 * kept + tile_bytes
+    fps_rank = K * F / dt
+    table, roof, ach = ({}, None, 0.0)
+    if kern:
+        table, roof, ach = kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / max(launches, 1),
+                                             B, N, upscale)
+    res = dict(value=fps_rank * world, ms_per_step=dt / K * 1e3, F=F, n_distinct=n_distinct, tl=tl, kappa=kappa,
+               alg_frame=alg_frame, fps_rank=fps_rank, kernels=table, roofline=roof, achieved=ach,
+               gather_verified=verified, gather_rates=gather_rates if world > 1 else None)
+    return res, pipe, text
+
+
+def short_config(job, name, B, N, F, K, W, tile, upscale):
+    """One of the other shapes, briefly: whole-pipeline rate and HBM fraction, the two largest kernels."""
+    res, pipe, text = measure(job, B, N, F, K, W, F, tile, upscale, "none", True)
+    kern = res["kernels"]
+    top = sorted(kern.items(), key=lambda kv: -kv[1]["share"])[:3]
+    out = dict(workload=f"synthetic {B}x{N} hex frames ({B * N} records, {res['tl']} text bytes each)" +
+                        (f", beam table up-scaled x{upscale} ({64 * upscale} entries, full grid; parity unpinned: the "
+                         f"reference admits 64 beams)" if upscale > 1 else ""),
+               value=round(res["value"], 2), unit="frames/s", frames_per_step=res["F"], steps=K, warmup=W,
+               ms_per_step=round(res["ms_per_step"], 4), kappa_kept_ratio=round(res["kappa"], 4),
+               alg_bytes_per_frame=int(res["alg_frame"]),
+               pipeline_alg_GBps=round(res["fps_rank"] * res["alg_frame"] / 1e9, 1),
+               pipeline_hbm_frac=round(res["fps_rank"] * res["alg_frame"] / 1e9 / HBM_PEAK_GBS, 4),
+               dominant_kernel=dict(name=res["roofline"]["kernel"], avg_launch_ms=res["roofline"]["avg_launch_ms"],
+                                    alg_GBps=res["roofline"]["achieved"], frac=res["roofline"]["frac"]),
+               top_kernels={k: dict(avg_ms=v["avg_ms"], share=v["share"], alg_GBps=v.get("alg_GBps")) for k, v in top})
+    del pipe, text
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -164,214 +437,71 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
         sys.exit(subprocess.run(cmd).returncode)
     cpu_line = None
-    if rank == 0 and world == 1 and a.cpu_frames > 0:      # before anything here initialises the GPU
+    if rank == 0 and a.cpu_frames > 0:      # rank 0 of any world size, before anything here initialises the GPU
         cpu_line = cpu_baseline(a.beams, a.samples, a.cpu_frames, a.tile)
-    local %= max(1, torch.cuda.device_count())          # ranks share GPUs only in a --backend gloo rehearsal
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
-    def gather_to_root(src, out_list):
-        """dist.gather of a device tensor to rank 0 (RCCL; through host memory under gloo)."""
-        if a.backend == "nccl":
-            dist.gather(src, out_list if rank == 0 else None, dst=0)
-            return
-        host = src.cpu()
-        tmp = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-        dist.gather(host, tmp, dst=0)
-        if rank == 0:
-            for o, t in zip(out_list, tmp):
-                o.copy_(t)
-
-    from slamhip import _lib, synth
-    from slamhip.pipeline import FramePipeline, default_mapping, expand_compact, synth_frames, viridis_lut
-
-    B, N, F, K, W = a.beams, a.samples, a.frames_per_step, a.steps, a.warmup
-    mapping, lut = default_mapping(), viridis_lut()
-    tl = synth.text_len(B, N)
-    stride = ((tl + 255) // 256) * 256
-    n_distinct = max(F, min(a.distinct_frames, (K + W) * F))
-    n_distinct = (n_distinct // F) * F
-    # fit the batch to the memory that is free: text ring + per frame about 2.5 x its text (row arrays, kept rows,
-    # library workspace; 89 MB measured for a 34.6 MB frame) + its tile slots
-    free_b, _total_b = torch.cuda.mem_get_info(dev)
-    per_frame = 2.5 * stride + a.tile * a.tile * 4 * (2 if (world > 1 and a.gather == "tiles") else 1) + (1 << 20)
-    need = n_distinct * stride + F * per_frame
-    if need > 0.92 * free_b:
-        scale = 0.92 * free_b / need
-        F = max(8, int(F * scale) // 8 * 8)
-        n_distinct = min(n_distinct, 2 * F) // F * F
-        print(f"bench: {free_b / 2**30:.0f} GiB free, batch reduced to {F} frames/step ({n_distinct} resident)", file=sys.stderr)
-    if world > 1:                                            # every rank runs the same batch size
-        ft = torch.tensor([F], dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
-        if int(ft.item()) != F:
-            F = int(ft.item())
-            n_distinct = min(n_distinct, 2 * F) // F * F
-    # frames of this rank: ids rank*n_distinct .. so every rank works on different data
-    text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=local)
+    job = Job(a)
+    B, N, K, W = a.beams, a.samples, a.steps, a.warmup
     gmode = "none" if (world == 1 or a.no_gather) else a.gather
-    gather = gmode != "none"
-    pipe = FramePipeline(F, tl, device=local, tile_w=a.tile, tile_h=a.tile, mapping=mapping, lut=lut,
-                         n_tile_slots=2 * F if gmode == "tiles" else F, n_compact_slots=2 if gather else 1)
-    pipe.set_uniform_layout(F, stride, tl)
-    ctx = pipe.ctx
-    torch.cuda.synchronize(dev)
-
-    comm_stream = torch.cuda.Stream(dev) if gather else None
-    recv = None
-    if gather and rank == 0:
-        if gmode == "tiles":
-            recv = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)]
-        else:
-            recv = [torch.empty_like(pipe.compact[0]) for _ in range(world)]
-    pending = []
-
-    def step(i):
-        batch = (i * F) % n_distinct
-        slot = (i % 2) * F if gmode == "tiles" else 0
-        cslot = i % 2 if gather else 0
-        pipe.run(text, text_base_offset=batch * stride, tile_slot=slot, compact_slot=cslot)
-        if gather:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                src = pipe.tiles[slot:slot + F] if gmode == "tiles" else pipe.compact[cslot]
-                gather_to_root(src, recv)
-                done = torch.cuda.Event()
-                done.record(comm_stream)
-            # the slot is reused two steps later: compute must wait for this gather
-            pending.append(done)
-            if len(pending) >= 2:
-                torch.cuda.current_stream(dev).wait_event(pending.pop(0))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for i in range(W):
-        step(i)
-    torch.cuda.synchronize(dev)
-    timing = not a.no_kernel_timing
-    if timing:
-        ctx.timing_reset()
-        ctx.timing(True)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(W + i)
-    torch.cuda.synchronize(dev)
-    barrier()
-    t1 = time.perf_counter()
-    kern = {}
-    if timing:
-        ctx.timing(False)
-        kern = ctx.timing_read()
-    dt = t1 - t0
-    gather_verified = None
-    if gmode == "compact":
-        # after the clock: the last batch's full tiles of every rank travel once, and rank 0 repaints the compact
-        # results it received for that batch; both must be the same bytes
-        full = [torch.empty((F, a.tile, a.tile, 4), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        gather_to_root(pipe.tiles[:F], full)
-        if rank == 0:
-            gather_verified = all(bool(torch.equal(expand_compact(recv[r], F, a.tile, a.tile), full[r])) for r in range(world))
-            del full
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # per-frame counts of the last batch for the byte accounting
-    st = pipe.stats_host().astype(np.int64)
-    nbytes = float(st[:, _lib.STAT_NBYTES].mean())
-    valid = float(st[:, _lib.STAT_VALID].mean())
-    kept = float(st[:, _lib.STAT_KEPT].mean())
-    assert int(st[:, _lib.STAT_NOT_STRICT].sum()) == 0
-    records = B * N
-    kappa = kept / max(valid, 1.0)
-    tile_bytes = a.tile * a.tile * 4
-    # algorithmic bytes per frame: read the text (3 per data byte), write decoded records (11 each),
-    # write kept rows (10 each), write the tile
-    alg_frame = 3.0 * nbytes + 11.0 * valid + 10.0 * kept + tile_bytes
-    fps_rank = K * F / dt
-    value = fps_rank * world
-
-    roof = None
-    kern_table = {}
-    if kern:
-        # algorithmic bytes each kernel must move per frame (its own inputs + outputs, no re-reads)
-        alg = {
-            "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
-            "tile_groups": 0.5 * valid,                      # 12 bits per 4 entries
-            "rows_finish": 10.0 * valid + 10.0 * kept,       # flag, ue, rss, clk in; kept rows out
-            "pivot": 6.0 * kept,
-            "raster": float(tile_bytes),
-        }
-        tot_ms = sum(ms for _, ms in kern.values())
-        for name, (launches, ms) in sorted(kern.items(), key=lambda kv: -kv[1][1]):
-            per = ms / max(launches, 1)
-            ent = dict(launches=launches, avg_ms=round(per, 5), share=round(ms / tot_ms, 4))
-            if name in alg:        # frames one launch covers: the library may cut a step into sub-batches
-                ent["alg_GBps"] = round(alg[name] * (F * K / max(launches, 1)) / (per * 1e-3) / 1e9, 1)
-            kern_table[name] = ent
-        dom = max((n for n in kern if n in alg), key=lambda n: kern[n][1])
-        per = kern[dom][1] / kern[dom][0]
-        fpl = F * K / kern[dom][0]                     # frames per launch of the dominant kernel
-        ach = alg[dom] * fpl / (per * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(pmc):      # HBM bytes per launch from the committed rocprofv3 PMC passes (same shape)
-            pj = json.load(open(pmc))
-            if pj.get("shape") == [B, N] and dom in pj["kernels"]:
-                kk = pj["kernels"][dom]
-                traffic = int((kk["fetch_bytes_per_frame"] + kk["write_bytes_per_frame"]) * fpl)
-        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                    alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
+    extra = ()
+    if world > 1 and gmode != "none":       # the other way of collecting results, timed after the headline
+        extra = ("tiles",) if gmode == "compact" else ("compact",)
+    res, pipe, text = measure(job, B, N, a.frames_per_step, K, W, a.distinct_frames, a.tile, a.upscale, gmode,
+                              not a.no_kernel_timing, extra)
+    F, roof = res["F"], res["roofline"]
 
     if cpu_line is not None:
         dump = cpu_line.pop("_dump")
         if os.path.exists(dump):
-            cpu_line["parity_check"] = parity_check(pipe, text, dump)
+            if a.upscale == 1:
+                cpu_line["parity_check"] = parity_check(pipe, text, dump)
             os.remove(dump)
             os.rmdir(os.path.dirname(dump))
     if roof is not None and rank == 0:
-        roof["measured_ceilings"] = measured_ceilings(ctx, pipe, ach)
+        roof["measured_ceilings"] = measured_ceilings(pipe.ctx, pipe, res["achieved"])
 
+    other = None
+    if world == 1 and not a.no_other_configs and (B, N, a.upscale) == (256, 4096, 1) and not a.no_kernel_timing:
+        # short passes over the other two synthetic shapes the benchmark is specified for, after the headline region;
+        # the headline's buffers are released first
+        del pipe, text
+        torch.cuda.empty_cache()
+        other = {}
+        for name, (b2, n2, f2, up2) in {"256x16384": (256, 16384, 200, 1), "1024x8192_up4": (1024, 8192, 100, 4),
+                                        "1024x8192": (1024, 8192, 100, 1)}.items():
+            try:
+                other[name] = short_config(job, name, b2, n2, f2, 5, 1, a.tile, up2)
+            except Exception as e:               # noqa: BLE001  (the headline line must still be printed)
+                other[name] = dict(error=f"{type(e).__name__}: {e}")
+
+    records = B * N
     out = {
         "metric": "frames/s (256-beam x 4096-sample decode+correct+raster)",
-        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "value": round(res["value"], 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"synthetic {B}x{N} hex frames ({records} records, {tl} text bytes each), "
-                               f"{F} frames/step, {n_distinct} distinct frames resident in HBM per GPU, "
-                               f"tile {a.tile}x{a.tile} RGBA",
+        "config": {"workload": f"synthetic {B}x{N} hex frames ({records} records, {res['tl']} text bytes each), "
+                               f"{F} frames/step, {res['n_distinct']} distinct frames resident in HBM per GPU, "
+                               f"tile {a.tile}x{a.tile} RGBA" + (f", beam table up-scaled x{a.upscale}" if a.upscale > 1 else ""),
                    "frames_per_step": F, "beams": B, "samples": N,
                    "parallelism": f"frames sharded over {world} GPU(s)" +
                                   {"none": "", "tiles": ", 4 MiB tiles gathered to rank 0 every step (RCCL)",
                                    "compact": ", tiles gathered to rank 0 every step in compact form (cell colours + "
                                               "pixel maps, repainted bit-exactly by slam_raster_dev; RCCL)"}[gmode],
-                   "gather": gmode, "gather_verified": gather_verified},
-        "kappa_kept_ratio": round(kappa, 4),
-        "alg_bytes_per_frame": int(alg_frame),
-        "pipeline_alg_GBps": round(fps_rank * alg_frame / 1e9, 1),
-        "pipeline_hbm_frac": round(fps_rank * alg_frame / 1e9 / HBM_PEAK_GBS, 4),
+                   "gather": gmode, "gather_verified": res["gather_verified"], "gather_rates": res["gather_rates"],
+                   "ranks_seen": job.ranks_seen, "comm": job.comm_version},
+        "kappa_kept_ratio": round(res["kappa"], 4),
+        "alg_bytes_per_frame": int(res["alg_frame"]),
+        "pipeline_alg_GBps": round(res["fps_rank"] * res["alg_frame"] / 1e9, 1),
+        "pipeline_hbm_frac": round(res["fps_rank"] * res["alg_frame"] / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roof,
-        "kernels": kern_table,
+        "kernels": res["kernels"],
+        "other_configs": other,
     }
     if rank == 0:
         out["cpu_baseline"] = cpu_line
         print(json.dumps(out))
     if world > 1:
-        dist.destroy_process_group()
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -727,3 +727,39 @@ def test_batch_driver_every_capture_over_four_ranks(tmp_path):
         assert (ln["valid"], ln["discarded"], ln["kept"]) == (e["valid"], e["discarded"], e["kept"]), e["name"]
         assert ln["grid"] == [len(e["aod"]), len(e["aoa"])]
         assert np.array_equal(np.asarray(Image.open(out / (e["name"][:-4] + "_tile.png"))), r["tile"]), e["name"]
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_full_figure_against_the_heatmaps_the_reference_committed(tmp_path, k):
+    """The drop-in process_excel_to_heatmap on the rows of a committed _filtered.xlsx writes a 1500 x 1200 figure
+    whose mesh shows, at every cell centre, the colour the reference's own committed PNG shows there
+    (debugDoc/heatmap_outputs/*_filtered_heatmap.png, sampled by tests/golden/make_committed_pngs.py); cells under a
+    dashed grid line excepted (fonts differ between hosts, so the axes box and with it the lines' pixels shift)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    from PIL import Image
+    from conftest import mesh_cells_agree, png_axes_box, png_cell_centres
+    import excel_heatmap_v3 as E
+    from slamhip import xlsx
+    z = np.load(os.path.join(GOLDEN, "committed_png_cells.npz"))
+    rows = z[f"f{k}_rows"].astype(np.int64)
+    name = str(z[f"f{k}_name"])
+    src = tmp_path / (name + "_filtered.xlsx")
+    xlsx.write_table(str(src), ["UE_Beam", "BS_Beam", "RSS值", "CLK值"],
+                     [rows[:, 0].tolist(), rows[:, 1].tolist(), rows[:, 2].tolist(), [0] * len(rows)])
+    m = {int(i): v for i, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    mp = tmp_path / "beam_angle.xlsx"
+    xlsx.write_table(str(mp), ["BeamID", "Angle"], [list(m.keys()), list(m.values())])
+    png = E.process_excel_to_heatmap(str(src), str(mp), use_log=False, blur_sigma=1.0, logger=_lg())   # the CLI's defaults
+    assert png == str(tmp_path / "heatmap_outputs" / (name + "_filtered_heatmap.png"))
+    img = np.array(Image.open(png).convert("RGBA"))
+    assert img.shape[:2] == tuple(z[f"f{k}_size"]) == (1200, 1500)
+    box = png_axes_box(img)
+    ref_box = z[f"f{k}_box"]
+    assert max(abs(a - b) for a, b in zip(box, ref_box)) <= 60, (box, ref_box)       # same layout up to font metrics
+    aod, aoa = z[f"f{k}_aod"], z[f"f{k}_aoa"]
+    px, py = png_cell_centres(box, O.edges(aoa), O.edges(aod))
+    mine = img[py[:, None], px[None, :]]
+    assert mine.shape == z[f"f{k}_cells"].shape
+    frac, bad_rows, bad_cols, rest_equal = mesh_cells_agree(mine[..., :3], z[f"f{k}_cells"][..., :3])
+    assert frac >= 0.94 and len(bad_rows) <= 2 and len(bad_cols) <= 2 and rest_equal, (frac, bad_rows, bad_cols)

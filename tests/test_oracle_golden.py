@@ -249,3 +249,22 @@ def test_oracle_on_every_capture_of_the_reference():
         fin = np.isfinite(blurred)
         assert np.array_equal(np.isfinite(mine), fin)
         assert np.max(np.abs(mine[fin] - blurred[fin]) / np.abs(blurred[fin])) <= 1e-14, e["name"]
+
+
+def test_oracle_colours_against_the_heatmaps_the_reference_committed():
+    """The three figures under debugDoc/heatmap_outputs (excel_heatmap_v3.py:425-471, CLI defaults), sampled at every
+    mesh cell centre by tests/golden/make_committed_pngs.py next to the rows of the matching _filtered.xlsx: the
+    oracle's pivot -> blur -> scale -> colour chain gives the same colour in every cell except along the row and the
+    column the figure's dashed grid line at 0 degrees runs through."""
+    from conftest import mesh_cells_agree
+    z = np.load(os.path.join(GOLDEN, "committed_png_cells.npz"))
+    mapping = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    lut = np.load(os.path.join(GOLDEN, "viridis_lut.npy"))
+    for k in range(3):
+        rows = z[f"f{k}_rows"].astype(np.int64)
+        mat, aod, aoa, s, c = O.pivot_mean(rows[:, 0], rows[:, 1], rows[:, 2], mapping)
+        assert aod == z[f"f{k}_aod"].tolist() and aoa == z[f"f{k}_aoa"].tolist()
+        r = O.render(mat, aod, aoa, lut, use_log=False, blur_sigma=1.0, W=8, H=8)
+        frac, bad_rows, bad_cols, rest_equal = mesh_cells_agree(r["cells"][..., :3], z[f"f{k}_cells"][..., :3])
+        assert frac >= 0.97 and len(bad_rows) <= 1 and len(bad_cols) <= 1 and rest_equal, (k, frac, bad_rows, bad_cols)
+        assert (z[f"f{k}_cells"][..., 3] == 255).all() and tuple(z[f"f{k}_size"]) == (1200, 1500)
