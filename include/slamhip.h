@@ -125,6 +125,14 @@ int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const i
                     const int16_t *beam_to_axis, int n_axis,
                     int64_t *sum, int64_t *cnt, double *matrix);
 
+/* The same pivot for RSS values that are not integers (the reference reads RSS with float(), excel_heatmap_v3.py:151-157,
+ * and averages whatever it finds): pandas' pivot_table(aggfunc=mean) (:297-299) adds a cell's values in row order with
+ * Kahan compensation and divides by their number, and so does this, bit for bit.  NaN values are not counted.
+ * sum: the compensated sums; cnt, matrix as in slam_pivot_mean. */
+int slam_pivot_mean_f64(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, size_t n,
+                        const int16_t *beam_to_axis, int n_axis,
+                        double *sum, int64_t *cnt, double *matrix);
+
 /* ---- a11-a12: NaN-aware Gaussian blur --------------------------------------------------------------
  * Replaces gaussian_kernel (:320-333) + gaussian_blur_nan_aware (:336-368): normalised
  * convolution, edge padding, NaN where the weight sum <= 1e-12.  h, w <= 4096; kernels of up to 127 taps

@@ -360,6 +360,39 @@ def pivot_mean(ue, bs, rss, mapping: Dict[int, float], upscale: int = 1):
     return mat, angles[rows].tolist(), angles[cols].tolist(), s, c
 
 
+def pivot_mean_float(ue, bs, rss, mapping: Dict[int, float]):
+    """compute_rssi_matrix (:286-314) for RSS values that are not whole numbers.  pandas' pivot_table(aggfunc=mean)
+    (pandas 2.x group_mean; not vendored in the reference, pinned by tests against the reference's own function) adds
+    the values of a cell in row order with Kahan compensation -- y = v - c; t = s + y; c = (t - s) - y, a NaN
+    compensation (infinite sums) reset to 0 -- skips NaN values, and divides the sum by the number added.
+    Returns (matrix over the angles that occur, aod_list, aoa_list, sum f64, cnt int64 on the full axis grid)."""
+    b2a, angles = axis_from_mapping(mapping)
+    n_axis = len(angles)
+    u, b = _i64(ue), _i64(bs)
+    r = np.ascontiguousarray(np.asarray(rss), dtype=np.float64)
+    s = np.zeros((n_axis, n_axis), np.float64)
+    comp = np.zeros((n_axis, n_axis), np.float64)
+    c = np.zeros((n_axis, n_axis), np.int64)
+    for i in range(len(u)):
+        if not (0 <= u[i] <= 63 and 0 <= b[i] <= 63) or r[i] != r[i]:
+            continue
+        col, row = int(b2a[u[i]]), int(b2a[b[i]])
+        if col < 0 or row < 0:
+            continue
+        with np.errstate(invalid="ignore", over="ignore"):
+            y = r[i] - comp[row, col]
+            t = s[row, col] + y
+            cc = (t - s[row, col]) - y
+        comp[row, col] = 0.0 if cc != cc else cc
+        s[row, col] = t
+        c[row, col] += 1
+    rows = np.flatnonzero(c.sum(axis=1) > 0)
+    cols = np.flatnonzero(c.sum(axis=0) > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        full = np.where(c > 0, s / np.maximum(c, 1), np.nan)
+    return full[np.ix_(rows, cols)], angles[rows].tolist(), angles[cols].tolist(), s, c
+
+
 # ---------------------------------------------------------------------------
 # a11-a12  gaussian_kernel (:320-333), gaussian_blur_nan_aware (:336-368)
 # ---------------------------------------------------------------------------

@@ -669,6 +669,39 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     return SLAM_OK;
 }
 
+extern "C" int slam_pivot_mean_f64(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, size_t n,
+                                   const int16_t *beam_to_axis, int n_axis, double *sum, int64_t *cnt, double *matrix)
+{
+    REQUIRE_CTX(ctx);
+    if (!beam_to_axis || n_axis < 1 || n_axis > SLAM_MAX_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean_f64: bad axis table");
+    if (n && (!ue || !bs || !rss)) return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean_f64: null column");
+    if (n > 0x7FFFFF00ull) return slam_fail(ctx, SLAM_E_RANGE, "too many rows");
+    for (int i = 0; i < 64; i++)
+        if (beam_to_axis[i] >= n_axis)
+            return slam_fail(ctx, SLAM_E_INVALID, "slam_pivot_mean_f64: beam_to_axis[%d] = %d is not below n_axis = %d", i,
+                             beam_to_axis[i], n_axis);
+    const size_t cells = (size_t)n_axis * n_axis;
+    ws_plan p;
+    const size_t ou = p.add(n * 4 + 4), ob = p.add(n * 4 + 4), orr = p.add(n * 8 + 8), oc = p.add(n * 4 + 4),
+                 ob2a = p.add(64 * sizeof(int16_t)), os = p.add(cells * 8), ok = p.add(cells * 4), om = p.add(cells * 8);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    SLAM_TRY(h2d(ctx, b + ou, ue, n * 4));
+    SLAM_TRY(h2d(ctx, b + ob, bs, n * 4));
+    SLAM_TRY(h2d(ctx, b + orr, rss, n * 8));
+    SLAM_TRY(h2d(ctx, b + ob2a, beam_to_axis, 64 * sizeof(int16_t)));
+    SLAM_TRY(pivot_kahan(ctx, (const int32_t *)(b + ou), (const int32_t *)(b + ob), (const double *)(b + orr), (uint32_t)n,
+                         (const int16_t *)(b + ob2a), n_axis, (int32_t *)(b + oc), (double *)(b + os), (uint32_t *)(b + ok),
+                         (double *)(b + om)));
+    std::vector<uint32_t> c32(cells);
+    if (sum) SLAM_TRY(d2h(ctx, sum, b + os, cells * 8));
+    SLAM_TRY(d2h(ctx, c32.data(), b + ok, cells * 4));
+    if (matrix) SLAM_TRY(d2h(ctx, matrix, b + om, cells * 8));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt) for (size_t i = 0; i < cells; i++) cnt[i] = c32[i];
+    return SLAM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // a11-a12: blur
 // ------------------------------------------------------------------------------------------------------

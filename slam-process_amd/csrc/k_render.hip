@@ -116,6 +116,57 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
     }
 }
 
+// ---- pivot of real-valued RSS ---------------------------------------------------------------------------------
+// pandas' pivot_table(aggfunc=mean) (compute_rssi_matrix, excel_heatmap_v3.py:297-299) sums every cell's values in
+// row order with Kahan compensation and divides by the count; for values that are not integers the result depends
+// on that order, so it is followed literally: k_cell_index gives every row its cell, then one wave per cell walks
+// the rows in order, finds its own by ballot and adds them one after the other.
+__global__ __launch_bounds__(256) void k_cell_index(const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
+                                                     const int16_t *beam_to_axis, int n_axis, int32_t *cell)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t u = ue[i], b = bs[i];
+    int32_t c = -1;
+    if (u >= 0 && u <= 63 && b >= 0 && b <= 63 && !isnan(rss[i])) {          // validate_beam_id; NaN values are not counted
+        const int cc = beam_to_axis[u], rr = beam_to_axis[b];
+        if ((uint32_t)cc < (uint32_t)n_axis && (uint32_t)rr < (uint32_t)n_axis) c = rr * n_axis + cc;
+    }
+    cell[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_pivot_kahan(const int32_t *cell, const double *rss, uint32_t n, int cells,
+                                                      double *sum, uint32_t *cnt, double *mean)
+{
+    const int mine = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (mine >= cells) return;
+    const uint32_t lane = lane_id();
+    double s = 0.0, comp = 0.0;
+    uint32_t k = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool hit = i < n && cell[i] == mine;
+        const double v = hit ? rss[i] : 0.0;
+        uint64_t m = __ballot(hit);
+        while (m) {                                       // the cell's rows of this stretch, in row order
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const double val = __longlong_as_double((long long)shfl64((uint64_t)__double_as_longlong(v), src));
+            const double y = val - comp;
+            const double t = s + y;
+            comp = (t - s) - y;
+            if (comp != comp) comp = 0.0;                 // an infinite sum leaves no compensation
+            s = t;
+            k++;
+        }
+    }
+    if (lane == 0) {
+        if (sum) sum[mine] = s;
+        if (cnt) cnt[mine] = k;
+        mean[mine] = k ? s / (double)k : __longlong_as_double(0x7FF8000000000000ll);
+    }
+}
+
 // ---- small-matrix device routines (one workgroup of 256 threads) --------------------------------------
 
 __device__ __forceinline__ bool finite_d(double v) { return !(isnan(v) || isinf(v)); }
@@ -686,6 +737,15 @@ int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, cons
     if (F == 0) return SLAM_OK;
     SLAM_LAUNCH(ctx, "raster", k_raster, raster_grid(W, H, F), dim3(256), cells, colmap, rowmap, W, H, stats, tile,
                 cell_stride);
+    return SLAM_OK;
+}
+
+int pivot_kahan(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
+                const int16_t *beam_to_axis, int n_axis, int32_t *cell, double *sum, uint32_t *cnt, double *mean)
+{
+    const int cells = n_axis * n_axis;
+    if (n) SLAM_LAUNCH(ctx, "cell_index", k_cell_index, dim3((n + 255) / 256), dim3(256), ue, bs, rss, n, beam_to_axis, n_axis, cell);
+    SLAM_LAUNCH(ctx, "pivot_kahan", k_pivot_kahan, dim3((cells + 3) / 4), dim3(256), cell, rss, n, cells, sum, cnt, mean);
     return SLAM_OK;
 }
 

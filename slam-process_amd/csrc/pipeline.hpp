@@ -184,6 +184,9 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
 
 // standalone small-matrix stages used by slam_pivot_mean / slam_blur_nan / slam_render (device pointers)
 int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt, int cells, double *matrix);
+// real-valued RSS: per cell the Kahan sum in row order, the count and the mean (cell: n int32 of scratch)
+int pivot_kahan(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
+                const int16_t *beam_to_axis, int n_axis, int32_t *cell, double *sum, uint32_t *cnt, double *mean);
 int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern, int ks, double *out);
 int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa, int use_log,
                 double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,

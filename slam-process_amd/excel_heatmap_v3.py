@@ -197,17 +197,20 @@ def compute_rssi_matrix(df: pd.DataFrame, logger: Optional[logging.Logger] = Non
     """Mean RSS per (AoD, AoA) over the angles that occur, NaN where a pair never occurs (reference :286-314)."""
     aod_vals = np.unique(df["AoD"].to_numpy(np.float64))
     aoa_vals = np.unique(df["AoA"].to_numpy(np.float64))
-    if len(aod_vals) > 64 or len(aoa_vals) > 64:
+    if len(aod_vals) > 64 or len(aoa_vals) > 64:      # beams are 0..63 (validate_beam_id), so a mapping gives at most 64
         raise ValueError("more than 64 distinct angles on an axis: beyond the device pivot's grid")
     rss = df["rss"].to_numpy(np.float64)
-    if not np.all(rss == np.round(rss)):
-        raise ValueError("non-integer RSS values: the device pivot keeps exact integer sums")
     r_idx = np.searchsorted(aod_vals, df["AoD"].to_numpy(np.float64))
     c_idx = np.searchsorted(aoa_vals, df["AoA"].to_numpy(np.float64))
     n_axis = max(len(aod_vals), len(aoa_vals))
     ident = np.full(64, -1, np.int16)
     ident[:n_axis] = np.arange(n_axis)
-    _s, _c, mean = ops.pivot_mean(c_idx, r_idx, rss.astype(np.int64), ident, n_axis)
+    if np.all(rss == np.round(rss)) and np.all(np.abs(rss) < 2.0 ** 31):
+        # whole numbers (every capture's RSS): exact integer sums, which is also what pandas' sum comes to
+        _s, _c, mean = ops.pivot_mean(c_idx, r_idx, rss.astype(np.int64), ident, n_axis)
+    else:
+        # fractions (dBm readings): pandas' compensated sum in row order, followed literally on the device
+        _s, _c, mean = ops.pivot_mean_f64(c_idx, r_idx, rss, ident, n_axis)
     matrix = np.ascontiguousarray(mean[: len(aod_vals), : len(aoa_vals)])
     if logger:
         logger.info(f"RSSI矩阵尺寸: {matrix.shape} (AoD: {len(aod_vals)} x AoA: {len(aoa_vals)})")

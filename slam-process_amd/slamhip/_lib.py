@@ -31,7 +31,7 @@ def cells_per_frame(n_axis: int) -> int:
 
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
-    "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean",
+    "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean", "slam_pivot_mean_f64",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
         lib.slam_correct.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, u32, vp, vp, C.c_int64,
                                      vp, vp, vp, vp, psz, vp, vp, vp, vp, vp, psz, psz]
         lib.slam_pivot_mean.argtypes = [vp, vp, vp, vp, sz, vp, C.c_int, vp, vp, vp]
+        lib.slam_pivot_mean_f64.argtypes = [vp, vp, vp, vp, sz, vp, C.c_int, vp, vp, vp]
         lib.slam_blur_nan.argtypes = [vp, vp, C.c_int, C.c_int, f64, vp]
         lib.slam_render.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, f64, f64, vp, vp, vp,
                                     C.c_int, C.c_int, vp]

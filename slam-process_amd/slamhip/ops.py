@@ -185,6 +185,22 @@ def pivot_mean(ue, bs, rss, beam_to_axis: np.ndarray, n_axis: int, device: int =
     return s, k, m
 
 
+def pivot_mean_f64(ue, bs, rss, beam_to_axis: np.ndarray, n_axis: int, device: int = 0):
+    """The pivot for RSS values of any kind (fractions, negative dBm): per cell pandas' compensated sum in row order,
+    the count and the mean, (sum f64, cnt int64, mean f64) on the full axis grid."""
+    c = _lib.ctx(device)
+    u, b = (_i32(x, n) for x, n in ((ue, "ue_beam"), (bs, "bs_beam")))
+    r = np.ascontiguousarray(rss, dtype=np.float64)
+    if len(r) != len(u):
+        raise ValueError("columns of different lengths")
+    b2a = np.ascontiguousarray(beam_to_axis, dtype=np.int16)
+    s = np.zeros((n_axis, n_axis), np.float64)
+    k = np.zeros((n_axis, n_axis), np.int64)
+    m = np.empty((n_axis, n_axis), np.float64)
+    c.check(c.lib.slam_pivot_mean_f64(c.h, ptr(u), ptr(b), ptr(r), len(u), ptr(b2a), int(n_axis), ptr(s), ptr(k), ptr(m)))
+    return s, k, m
+
+
 def blur_nan(data: np.ndarray, sigma: float, device: int = 0) -> np.ndarray:
     """gaussian_blur_nan_aware's data path."""
     c = _lib.ctx(device)

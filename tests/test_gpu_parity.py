@@ -1366,3 +1366,37 @@ def test_workspace_cannot_move_under_a_captured_graph(mapping, lut):
     torch.cuda.synchronize()
     assert torch.equal(pipe.tiles, want[0]) and torch.equal(pipe.stats, want[1])
     pipe.ctx.check(pipe.ctx.lib.slam_pin_workspace(pipe.ctx.h, 0))
+
+
+def test_float_rss_pivot_follows_pandas(ops, mapping):
+    """RSS values that are not whole numbers through slam_pivot_mean_f64 and through the drop-in compute_rssi_matrix:
+    bit for bit what the reference's compute_rssi_matrix returned for the same tables (fixture made by
+    tests/golden/make_float_pivot.py from the reference's own function), and what the oracle gives on random ones."""
+    import pandas as pd
+    import excel_heatmap_v3 as E
+    z = np.load(os.path.join(GOLDEN, "float_pivot.npz"))
+    b2a, angles = ops.axis_from_mapping(mapping)
+    for name in ("dbm", "mixed_scales", "few_cells", "infinities", "halves"):
+        ue, bs, rss, want = z[name + "_ue"], z[name + "_bs"], z[name + "_rss"], z[name + "_matrix"]
+        s, c, m = ops.pivot_mean_f64(ue, bs, rss, b2a, len(angles))
+        rows, cols = np.flatnonzero(c.sum(1) > 0), np.flatnonzero(c.sum(0) > 0)
+        got = m[np.ix_(rows, cols)]
+        assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want)), name
+        assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64)), name
+        so, co = O.pivot_mean_float(ue, bs, rss, mapping)[3:]
+        assert np.array_equal(c, co) and np.array_equal(s.view(np.uint64), so.view(np.uint64)), name
+        df = pd.DataFrame({"ue_beam": ue.astype(np.int64), "bs_beam": bs.astype(np.int64), "rss": rss})
+        mat, aod, aoa = E.compute_rssi_matrix(E.map_angles(df, mapping))
+        assert aod == z[name + "_aod"].tolist() and aoa == z[name + "_aoa"].tolist()
+        assert np.array_equal(mat[~np.isnan(mat)].view(np.uint64), want[~np.isnan(want)].view(np.uint64)), name
+    rng = np.random.default_rng(3)
+    mp = {i: float(i // 2) for i in range(0, 64) if i % 7}               # duplicate angles and unmapped beams
+    b2a, angles = ops.axis_from_mapping(mp)
+    for trial in range(6):
+        n = int(rng.integers(0, 30000))
+        ue, bs = rng.integers(-2, 66, n), rng.integers(-2, 66, n)        # some beams outside 0..63
+        rss = rng.normal(-70, 20, n) * rng.choice([1.0, 1e-5, 1e7], n)
+        rss[rng.random(n) < 0.01] = np.nan
+        s, c, m = ops.pivot_mean_f64(ue, bs, rss, b2a, len(angles))
+        so, co = O.pivot_mean_float(ue, bs, rss, mp)[3:]
+        assert np.array_equal(c, co) and np.array_equal(s.view(np.uint64), so.view(np.uint64)), trial

@@ -268,3 +268,24 @@ def test_oracle_colours_against_the_heatmaps_the_reference_committed():
         frac, bad_rows, bad_cols, rest_equal = mesh_cells_agree(r["cells"][..., :3], z[f"f{k}_cells"][..., :3])
         assert frac >= 0.97 and len(bad_rows) <= 1 and len(bad_cols) <= 1 and rest_equal, (k, frac, bad_rows, bad_cols)
         assert (z[f"f{k}_cells"][..., 3] == 255).all() and tuple(z[f"f{k}_size"]) == (1200, 1500)
+
+
+FLOAT_TABLES = ("dbm", "mixed_scales", "few_cells", "infinities", "halves")
+
+
+def test_oracle_float_pivot_against_the_reference_fixture():
+    """RSS values that are not whole numbers: the oracle's restatement of pandas' compensated, row-ordered cell sums
+    against matrices the reference's own compute_rssi_matrix returned (tests/golden/make_float_pivot.py), bit for bit."""
+    z = np.load(os.path.join(GOLDEN, "float_pivot.npz"))
+    mapping = {int(k): v for k, v in json.load(open(os.path.join(GOLDEN, "beam_angle.json"))).items()}
+    for name in FLOAT_TABLES:
+        mat, aod, aoa, s, c = O.pivot_mean_float(z[name + "_ue"], z[name + "_bs"], z[name + "_rss"], mapping)
+        assert aod == z[name + "_aod"].tolist() and aoa == z[name + "_aoa"].tolist(), name
+        want = z[name + "_matrix"]
+        assert np.array_equal(np.isnan(mat), np.isnan(want)), name
+        assert np.array_equal(mat.view(np.uint64)[~np.isnan(mat)], want.view(np.uint64)[~np.isnan(want)]), name
+    # whole numbers: the compensated sum is the exact integer sum
+    rows = np.load(os.path.join(GOLDEN, "log0.npz"))["kept"]
+    a = O.pivot_mean_float(rows[:, 0], rows[:, 1], rows[:, 2].astype(np.float64), mapping)
+    b = O.pivot_mean(rows[:, 0], rows[:, 1], rows[:, 2], mapping)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[4], b[4])

@@ -204,3 +204,33 @@ def test_heatmap_command_line_options_equal_the_references():
                       for a in parser._actions)
 
     assert options(R.build_arg_parser()) == options(M.build_arg_parser())
+
+
+def test_float_pivot_against_the_reference():
+    """compute_rssi_matrix of the reference (pandas pivot_table mean) on random tables of fractional RSS against the
+    oracle's restatement (compensated sums in row order): equal bit for bit, whatever the row order."""
+    import importlib.util
+    import warnings
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    spec = importlib.util.spec_from_file_location("ref_excel_heatmap_v3_fp", os.path.join(REFERENCE, "excel_heatmap_v3.py"))
+    E = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(E)
+    rng = np.random.default_rng(99)
+    mapping = {i: -43.6 + 1.4 * i for i in range(64) if i % 9}          # some beams unmapped
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for trial in range(12):
+            n = int(rng.integers(1, 4000))
+            ue, bs = rng.integers(0, 64, n), rng.integers(0, 64, n)
+            rss = rng.normal(-70, 20, n) * rng.choice([1.0, 1e-5, 1e7], n)
+            df = pd.DataFrame({"ue_beam": ue, "bs_beam": bs, "rss": rss})
+            try:
+                want, aod, aoa = E.compute_rssi_matrix(E.map_angles(df, mapping))
+            except ValueError:
+                continue
+            got, aod_o, aoa_o, s, c = O.pivot_mean_float(ue, bs, rss, mapping)
+            assert aod == aod_o and aoa == aoa_o
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            assert np.array_equal(got[~np.isnan(got)].view(np.uint64), want[~np.isnan(want)].view(np.uint64)), trial
