@@ -151,9 +151,9 @@ def measured_ceilings(ctx, pipe, achieved_gbs):
                 probe_bytes=n, frac_of_read3_write1=round(achieved_gbs / mix, 4))
 
 
-# The two builds of the fused correction kernel share one job: frames (or workgroups) the lean build leaves go to the
-# full one, so their times add up against one set of algorithmic bytes.
-KERNEL_GROUPS = {"rows_finish": ("rows_finish", "rows_finish_rest")}
+# The three builds of the fused correction kernel share one job: frames (or workgroups) the lean build leaves go to
+# the mid or the full one, so their times add up against one set of algorithmic bytes.
+KERNEL_GROUPS = {"rows_finish": ("rows_finish", "rows_finish_mid", "rows_finish_rest")}
 
 
 def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_of, B, N, upscale):

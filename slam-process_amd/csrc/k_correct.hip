@@ -140,7 +140,15 @@ __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, u
     const uint32_t i0 = tile * ROWS_PER_BLOCK + tid * 4;
     row_bits(in, (size_t)f * in.row_cap, sp, i0, one_group, &bound, &base, &live, &prev);
     // the later row kernels take these bits instead of reading the columns again
-    if (i0 < sp.n) rmask[((size_t)f * in.row_cap + i0) >> 2] = (uint16_t)(bound | (base << 4) | (live << 8));
+    uint32_t flag1 = 0;
+    if (live) {
+        T8 fl[4];
+        load4(in.flag + (size_t)f * in.row_cap + i0, fl);
+#pragma unroll
+        for (int k = 0; k < 4; k++) flag1 |= (uint32_t)(fl[k] == 1) << k;
+        flag1 &= live;
+    }
+    if (i0 < sp.n) rmask[((size_t)f * in.row_cap + i0) >> 2] = (uint16_t)(bound | (base << 4) | (live << 8) | (flag1 << 12));
     uint32_t cb = wave_sum(__popc(bound)), cl = wave_sum(__popc(base));
     if (lane_id() == 0) { sh[tid >> 6] = cb; sh[4 + (tid >> 6)] = cl; }
     __syncthreads();
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
         const uint32_t mk = ws.rmask[(fb + i0) >> 2];
         bound = mk & 15u;
         base = (mk >> 4) & 15u;
-        live = mk >> 8;
+        live = (mk >> 8) & 15u;
         if (base & 1u) live4(sp, i0, &prev);          // a baseline's clock is that of the row before it
     }
     uint32_t tot;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int al
         for (uint32_t ps = 0; ps < (SLOT_ROWS + 63) / 64; ps++) {
             const uint32_t e = lane + 64u * ps, i = t * SLOT_ROWS + e;
             const bool live = e < C;
-            bool b = false, bl = false;
+            bool b = false, bl = false, f1 = false;
             uint32_t pck = 0, bsv = 0;
             if (live) {
                 uint32_t prev = i - 1;
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int al
                 const uint32_t uev = (uint32_t)in.ue[fb + i], flg = (uint32_t)in.flag[fb + i];
                 const uint32_t rsv = (uint32_t)in.rss[fb + i];
                 bsv = (uint32_t)in.bs[fb + i];
+                f1 = flg == 1u;
                 if (prev == NO_ROW) {
                     b = true;
                 } else {
@@ -291,6 +300,7 @@ __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int al
                 }
             }
             const uint64_t bm = __ballot(b), lm = __ballot(bl), vm = __ballot(live);
+            const uint64_t fm = __ballot(f1);
             if (bl) {
                 const uint32_t idx = nbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
                 pay[idx] = (unsigned long long)pck | ((unsigned long long)bsv << 32) | ((unsigned long long)e << 40);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int al
             const uint32_t grp = 16u * ps + lane;
             if (lane < 16 && grp < SLOT_ROWS / 4)
                 rm[grp] = (uint16_t)(((bm >> (4 * lane)) & 15u) | (((lm >> (4 * lane)) & 15u) << 4) |
-                                     (((vm >> (4 * lane)) & 15u) << 8));
+                                     (((vm >> (4 * lane)) & 15u) << 8) | (((fm >> (4 * lane)) & 15u) << 12));
         }
         if (lane == 0) {
             in.bits.nbound[tix] = nbound;
@@ -403,6 +413,7 @@ __device__ __forceinline__ unsigned long long baseline_from_tiles(const tile_bit
 
 constexpr uint32_t WAVE_SORT_MAX = 64;      // groups of up to this many baselines are sorted by one wave in registers
 constexpr uint32_t MID_SORT_MAX = 256;      // ... and up to this many by one wave in its own piece of LDS
+constexpr uint32_t MID_TAB_CAP = 512;       // phase tables below this length fit the LDS of k_rows_finish's mid build
 
 // LDS written by some lanes of a wave and read by others of the SAME wave: the hardware runs a wave's LDS
 // operations in order, so only the compiler has to be told not to move them across this point.
@@ -465,7 +476,8 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
         }
         // in the batched path rt_nbase is free: its entry f tells k_rows_finish that frame f has a group whose phase
         // table may not fit a wave's registers (bit 0) and k_bl_sort that one is left for it to sort (bit 2)
-        if (m > WAVE_SORT_MAX && bits.pay && lane == 0) atomicOr(ws.rt_nbase + f, m > MID_SORT_MAX ? 5u : 1u);
+        if (m > WAVE_SORT_MAX && bits.pay && lane == 0)      // bit 3: a table the mid build of k_rows_finish cannot hold
+            atomicOr(ws.rt_nbase + f, (m > MID_SORT_MAX ? 5u : 1u) | (m >= MID_TAB_CAP ? 8u : 0u));
         if (m > MID_SORT_MAX) continue;
         if (m > WAVE_SORT_MAX) {
             unsigned long long *kk = mid_keys[threadIdx.x >> 6];
@@ -774,6 +786,7 @@ template <>
 struct corr_none<int32_t> { static constexpr int32_t v = -1; };
 
 constexpr int TAB_CAP = 1024;         // phases of one group staged in LDS by k_rows_correct
+
 constexpr uint32_t TAB_MAX_GROUPS = 16; // tiles spanning more groups than this search the tables in global memory
 
 // Corrected BS for a row (clk div cycle = q1, clk mod cycle = r) against the chosen baseline (clk_b div cycle = qb,
@@ -857,7 +870,7 @@ __global__ __launch_bounds__(256) void k_rows_correct(rows_in_t<T8, T32> in, uin
     if (i0 < n) {
         const uint32_t mk = ws.rmask[(fb + i0) >> 2];
         bound = mk & 15u;
-        live = mk >> 8;
+        live = (mk >> 8) & 15u;
     }
     uint32_t tot;
     const uint32_t ex = block_excl_scan(__popc(bound), sh, &tot);
@@ -975,7 +988,11 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 // group ids come from the bits k_rows_summarize left per 4 entries, the four rows of a thread search their
 // group's LDS-staged phase table in lock step (fixed trip count over the table padded to a power of two), and a
 // kept row goes straight to the front of its block's entries.
-constexpr int FIN_TPB = 3;            // consecutive blocks of entries one workgroup of k_rows_finish walks
+constexpr int FIN_TPB = 3;            // consecutive blocks of entries one workgroup of k_rows_finish walks (lean build)
+#ifndef SLAM_FIN_TPB_FULL
+#define SLAM_FIN_TPB_FULL 3
+#endif
+constexpr int FIN_TPB_FULL = SLAM_FIN_TPB_FULL;       // ... and the full build
 
 // v of the lane whose byte address (4 * lane, below 256) is given: a bare ds_bpermute, without the lane
 // arithmetic __shfl adds for sub-wave widths.
@@ -991,66 +1008,83 @@ __device__ __forceinline__ void unpack4(const V &q, T v[4])
 }
 
 //
-// Two builds of one body.  LEAN holds only the common case -- every phase table of the frame fits a wave's registers
-// (no group above 64 baselines: bit 0 of the frame's flags clear), the tolerance is below half a cycle, the workgroup
-// touches fewer than TAB_MAX_GROUPS groups -- which keeps it at 80 VGPRs and 10 KiB of LDS, six waves per SIMD.  It
-// leaves a frame with a large group alone; a workgroup spanning too many groups sets its flag in `defer` (and bit 1 of
-// the frame's flags) and leaves.  The full build has every path; given `defer` it serves only those frames and
-// workgroups, and where a frame's flags are zero -- the usual case -- its workgroups leave after one load.
-template <typename T8, typename T32, bool LEAN>
+// Three builds of one body.  The kernel is bound by occupancy as much as by anything (halving its waves per SIMD costs
+// 68 %), so the common cases each get a build that holds only their own paths:
+//   LEAN  every phase table of the frame fits a wave's registers (no group above 64 baselines: bit 0 of the frame's
+//         flags clear), tolerance below half a cycle: 80 VGPRs, 10 KiB of LDS, six waves per SIMD;
+//   MID   frames with larger groups whose tables all stay below MID_TAB_CAP phases (bit 0 set, bit 3 clear), same
+//         tolerance rule: every table, small ones included, is searched in LDS;
+//   FULL  every path (tables in registers, LDS or global memory, any tolerance, any modulus).
+// LEAN and MID leave a workgroup that spans TAB_MAX_GROUPS groups or more to FULL: they set its flag in `defer` and bit 1
+// of the frame's flags.  Given `defer`, FULL serves only those workgroups and the frames with bit 3 set; where no bit
+// asks for it -- the usual case -- its workgroups leave after one load.
+enum { FIN_LEAN = 0, FIN_MID = 1, FIN_FULL = 2 };
+template <typename T8, typename T32, int MODE, int TPB>
 __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint32_t rt_max, const uint32_t *rt_gbase,
                                                       correct_ws ws, correct_params prm, kept_out_t<T8, T32> out,
                                                       uint32_t *stats, uint32_t *defer, uint32_t *frame_flags)
 {
+    constexpr bool LEAN = MODE == FIN_LEAN, MID = MODE == FIN_MID, FULL = MODE == FIN_FULL;
+    constexpr uint32_t CAP = MID ? MID_TAB_CAP : (uint32_t)TAB_CAP;
     using V8 = typename vec4_of<T8>::type;
     using V32 = typename vec4_of<T32>::type;
     __shared__ uint32_t sh[17];
-    __shared__ uint32_t t_rb[LEAN ? 1 : TAB_CAP];
-    __shared__ uint4 t_pay[LEAN ? 1 : TAB_CAP];
+    __shared__ uint32_t t_rb[LEAN ? 1 : CAP];
+    __shared__ uint4 t_pay[LEAN ? 1 : CAP];
     __shared__ uint32_t g_nd[TAB_MAX_GROUPS], g_bl[TAB_MAX_GROUPS];
     __shared__ uint32_t wave_tot[2][4];                   // kept rows per wave, double-buffered over the blocks walked
     __shared__ __attribute__((aligned(16))) T32 k_rs[ROWS_PER_BLOCK], k_ck[ROWS_PER_BLOCK];   // kept rows of a block, packed
     __shared__ __attribute__((aligned(16))) T8 k_ue[ROWS_PER_BLOCK], k_bs[ROWS_PER_BLOCK];
-    const uint32_t f = blockIdx.y, bx = blockIdx.x, tile0 = bx * FIN_TPB, tid = threadIdx.x;
+    const uint32_t f = blockIdx.y, bx = blockIdx.x, tile0 = bx * TPB, tid = threadIdx.x;
+    bool only_deferred = false;                          // full build: serve only the blocks of workgroups that deferred
     if (defer) {
-        const uint32_t ff = frame_flags[f];              // bit 0: a group above 64 baselines; bit 1: a workgroup deferred
-        if (LEAN ? (ff & 1u) != 0 : ff == 0) return;
-        if (!LEAN && !(ff & 1u) && !defer[(size_t)f * rt_max + bx]) return;
+        // bit 0: a group above 64 baselines; bit 1: a workgroup deferred; bit 3: a table of MID_TAB_CAP phases or more
+        const uint32_t ff = frame_flags[f];
+        if (LEAN && (ff & 1u)) return;
+        if (MID && (!(ff & 1u) || (ff & 8u))) return;
+        if (FULL && !(ff & 10u)) return;
+        if (FULL && !(ff & 8u)) {
+            only_deferred = true;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < TPB; j++)
+                if (tile0 + j < rt_max) any = any || defer[(size_t)f * rt_max + (tile0 + j) / FIN_TPB] != 0;
+            if (!any) return;
+        }
     }
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     if (tile0 * ROWS_PER_BLOCK >= n) return;
     const size_t fb = (size_t)f * in.row_cap;
-    // every load of the workgroup's FIN_TPB blocks of entries is issued up front
-    uint32_t mk[FIN_TPB], gb[FIN_TPB + 1];
-    V8 flv[FIN_TPB], uev[FIN_TPB];
-    V32 ckv[FIN_TPB], rsv[FIN_TPB];
+    // every load of the workgroup's TPB blocks of entries is issued up front
+    uint32_t mk[TPB], gb[TPB + 1];
+    V8 uev[TPB];
+    V32 ckv[TPB], rsv[TPB];
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
 #pragma unroll
-    for (int j = 0; j < FIN_TPB; j++) {
+    for (int j = 0; j < TPB; j++) {
         const uint32_t i0 = (tile0 + j) * ROWS_PER_BLOCK + tid * 4;
         mk[j] = 0;
         if (i0 < n) {
-            mk[j] = ws.rmask[(fb + i0) >> 2];
-            flv[j] = *reinterpret_cast<const V8 *>(in.flag + fb + i0);
+            mk[j] = ws.rmask[(fb + i0) >> 2];          // the FLAG == 1 bits come with the mask: the flag column is not read
             ckv[j] = *reinterpret_cast<const V32 *>(in.clk + fb + i0);
             uev[j] = *reinterpret_cast<const V8 *>(in.ue + fb + i0);
             rsv[j] = *reinterpret_cast<const V32 *>(in.rss + fb + i0);
         }
     }
 #pragma unroll
-    for (int j = 0; j <= FIN_TPB; j++)        // groups started before each block (exclusive bases; G past the end)
+    for (int j = 0; j <= TPB; j++)        // groups started before each block (exclusive bases; G past the end)
         gb[j] = (tile0 + j) * ROWS_PER_BLOCK < n ? rt_gbase[(size_t)f * rt_max + tile0 + j] : G;
     // groups the workgroup touches: the one running into it and those starting in it
     const size_t gs = (size_t)f * (in.row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
-    const uint32_t glo_all = gb[0] ? gb[0] - 1 : 0, ghi_all = gb[FIN_TPB] - 1;
+    const uint32_t glo_all = gb[0] ? gb[0] - 1 : 0, ghi_all = gb[TPB] - 1;
     const bool staged = (ghi_all - glo_all) < TAB_MAX_GROUPS;
     if (staged && tid <= ghi_all - glo_all) {
         g_nd[tid] = ws.grp_nd[gs + glo_all + tid];
         g_bl[tid] = ws.grp_bl[gs + glo_all + tid];
     }
     __syncthreads();
-    if (LEAN) {
+    if (!FULL) {
         if (tid == 0) {
             defer[(size_t)f * rt_max + bx] = staged ? 0u : 1u;
             if (!staged) atomicOr(frame_flags + f, 2u);
@@ -1061,13 +1095,17 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     uint32_t in_reg_group = 0xFFFFFFFFu, t_r = 0xFFFFFFFFu, t_x = 0, t_y = 0, t_z = 0;   // small table: entry `lane`
     uint32_t pv[7] = {0, 0, 0, 0, 0, 0, 0};              // its entries 7, 15, ..., 55 (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < FIN_TPB; j++) {
+    for (int j = 0; j < TPB; j++) {
         const uint32_t tile = tile0 + j;
         if (tile * ROWS_PER_BLOCK >= n) break;
-        const uint32_t bound = mk[j] & 15u, live = mk[j] >> 8;
-        T8 fl[4] = {1, 1, 1, 1}, ue[4] = {0, 0, 0, 0};
+        if (FULL && only_deferred && !defer[(size_t)f * rt_max + tile / FIN_TPB]) continue;     // another build did this block
+        const uint32_t bound = mk[j] & 15u, live = (mk[j] >> 8) & 15u;
+        // fl[k] == 1: the entry takes no part (a FLAG = 1 row, or not a row at all)
+        const uint32_t skip = ((mk[j] >> 12) | ~live) & 15u;
+        uint32_t fl[4] = {skip & 1u, (skip >> 1) & 1u, (skip >> 2) & 1u, (skip >> 3) & 1u};
+        T8 ue[4] = {0, 0, 0, 0};
         T32 ck[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0};
-        if (live) { unpack4(flv[j], fl); unpack4(ckv[j], ck); unpack4(uev[j], ue); unpack4(rsv[j], rs); }
+        if (live) { unpack4(ckv[j], ck); unpack4(uev[j], ue); unpack4(rsv[j], rs); }
         // rows before this thread's that start a group: none in most blocks (the bases say so without a scan)
         uint32_t ex = 0;
         if (gb[j + 1] != gb[j]) {
@@ -1084,18 +1122,17 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                 if ((bound >> k) & 1u) g++;
                 gi[k] = g - 1;
                 res[k] = -1;
-                if (!((live >> k) & 1u)) fl[k] = 1;               // entries that are not rows take no part
                 phase_of((int32_t)ck[k], prm, &q1[k], &r1[k]);
             }
         }
         uint32_t keep = 0;
-        if (LEAN || staged) {
+        if (!FULL || staged) {
             for (uint32_t gg = glo; gg <= ghi; gg++) {
                 const uint32_t nd = g_nd[gg - glo_all];
                 if (nd == 0) continue;                              // block-uniform
                 const uint32_t *grb = ws.srt_rb + bsb + g_bl[gg - glo_all];
                 const uint4 *gpay = ws.srt_pay + bsb + g_bl[gg - glo_all];
-                if (nd <= 64) {
+                if (!MID && nd <= 64) {
                     // the whole table in registers, one entry per lane; lookups are lane permutes (no LDS banks).
                     // A wave none of whose rows belongs to this group skips it (no barrier on this path): in a
                     // block that spans two groups only the wave holding the boundary searches twice.
@@ -1178,10 +1215,10 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                     }
                 } else if (LEAN) {
                     // not reached: such a workgroup has deferred
-                } else if (nd < TAB_CAP) {
+                } else if (MID || nd < CAP) {                       // (the mid build only sees frames whose tables all fit)
                     if (in_lds_group != gg) {                       // consecutive blocks mostly stay in one group
                         __syncthreads();
-                        P = 2;                                      // power of two > nd: the padded table length
+                        P = 8;                                      // power of two > nd, at least 8: the padded table length
                         while (P <= nd) P <<= 1;
                         for (uint32_t i = tid; i < P; i += 256) {
                             t_rb[i] = i < nd ? grb[i] : 0xFFFFFFFFu;
@@ -1190,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                         __syncthreads();
                         in_lds_group = gg;
                         // the seven entries the first three levels of every search compare against, kept in scalar
-                        // registers (P >= 128 here); the register table's copies are gone with them
+                        // registers; the register table's copies are gone with them
                         const uint32_t e8 = P >> 3;
 #pragma unroll
                         for (int i = 0; i < 7; i++) pv[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_rb[e8 * (i + 1) - 1]);
@@ -1210,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
 #pragma unroll
                         for (int k = 0; k < 4; k++) lo[k] += t_rb[lo[k] + h - 1] < r1[k] ? h : 0u;
                     }
-                    if (prm.small_tol) {
+                    if (MID || prm.small_tol) {
                         // as in the register path: with 0 <= 2*tol < cycle the forward distance to the successor and
                         // the backward distance to the predecessor are the residuals; only the winner's payload is read
                         const uint32_t cyc = (uint32_t)prm.cycle;
@@ -1235,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                             if (decide_phase(t_rb, t_pay, nd, lo[k], q1[k], r1[k], prm, &bsn)) { res[k] = bsn; keep |= 1u << k; }
                         }
                     }
-                } else {
+                } else if (FULL) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (fl[k] == 1 || gi[k] != gg) continue;
@@ -1244,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
                     }
                 }
             }
-        } else {
+        } else if (FULL) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (fl[k] == 1) continue;
@@ -1387,17 +1424,21 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                     (uint32_t)SLOT_ROWS);
         SLAM_LAUNCH(ctx, "tile_groups", (k_tile_groups<T8, T32>), dim3((st_max + 255) / 256, F), block, in, w2, rt_max,
                     ws.rt_nbound, stats);
+        // 64 workgroups a frame (four groups per wave at 1024 groups): 128, 256 and 512 measured 10 - 15 % slower
         SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), w2, in.row_cap, prm,
                     stats, in.bits);
         SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), w2, in.row_cap, prm, stats,
                     in.bits, MID_SORT_MAX);
         // the lean build first; what it defers (large groups, a tolerance of half a cycle or more) goes to the full one
         uint32_t *defer = prm_k.small_tol ? ws.rt_nkept : nullptr;
-        const uint32_t wgs = (rt_max + FIN_TPB - 1) / FIN_TPB;
-        if (defer)
-            SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32, true>), dim3(wgs, F), block, in, rt_max, ws.rt_nbound,
-                        w2, prm_k, out, stats, defer, ws.rt_nbase);
-        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, false>), dim3(wgs, F), block,
+        const uint32_t wgs = (rt_max + FIN_TPB - 1) / FIN_TPB, wgs_full = (rt_max + FIN_TPB_FULL - 1) / FIN_TPB_FULL;
+        if (defer) {
+            SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32, FIN_LEAN, FIN_TPB>), dim3(wgs, F), block, in, rt_max,
+                        ws.rt_nbound, w2, prm_k, out, stats, defer, ws.rt_nbase);
+            SLAM_LAUNCH(ctx, "rows_finish_mid", (k_rows_finish<T8, T32, FIN_MID, FIN_TPB>), dim3(wgs, F), block, in, rt_max,
+                        ws.rt_nbound, w2, prm_k, out, stats, defer, ws.rt_nbase);
+        }
+        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, FIN_FULL, FIN_TPB_FULL>), dim3(wgs_full, F), block,
                     in, rt_max, ws.rt_nbound, w2, prm_k, out, stats, defer, ws.rt_nbase);
         return SLAM_OK;
     }
@@ -1415,7 +1456,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
-        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, false>), dim3((rt_max + FIN_TPB - 1) / FIN_TPB, F), block,
+        SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, FIN_FULL, FIN_TPB_FULL>), dim3((rt_max + FIN_TPB_FULL - 1) / FIN_TPB_FULL, F), block,
                     in, rt_max, ws.rt_nbound, ws, prm_k, out, stats, (uint32_t *)nullptr, (uint32_t *)nullptr);
         return SLAM_OK;
     }

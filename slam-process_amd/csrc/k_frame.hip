@@ -787,7 +787,9 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
                 const uint32_t bound = __builtin_amdgcn_udot4(bnd7, 0x08040201u, 0u, false) >> 7;
                 const uint32_t base = __builtin_amdgcn_udot4(bas7, 0x08040201u, 0u, false) >> 7;
                 const uint32_t live = __builtin_amdgcn_udot4(liv7, 0x08040201u, 0u, false) >> 7;
-                if (g < NG) rm[g] = (uint16_t)(bound | (base << 4) | (live << 8));
+                // FLAG == 1 bits ride in the top nibble, so the correction need not read the flag column again
+                const uint32_t flag1 = g < NG ? (__builtin_amdgcn_udot4(s1[g] & 0x01010101u, 0x08040201u, 0u, false) & live) : 0u;
+                if (g < NG) rm[g] = (uint16_t)(bound | (base << 4) | (live << 8) | (flag1 << 12));
                 const uint32_t c = __popc(base);                                   // 0, 1 or 2 baselines in four rows
                 const uint64_t m1 = __ballot(c >= 1u), m2 = __ballot(c >= 2u);
                 if (c) {

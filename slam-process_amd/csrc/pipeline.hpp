@@ -45,7 +45,8 @@ struct frame_ws {               // device scratch of the framing stage
 
 // What the correction needs to know about neighbouring rows, produced per framing tile while the tile's records
 // are still on chip (single-pass framing) or from the row arrays (k_tile_bits):
-//   rmask   per 4 entries: group-start bits | baseline bits << 4 | is-a-row bits << 8 (frame f at f*row_cap/4)
+//   rmask   per 4 entries: group-start bits | baseline bits << 4 | is-a-row bits << 8 | FLAG == 1 bits << 12
+//           (frame f at f*row_cap/4)
 //   nbound / nbase  per tile: rows that start a group / are baselines (bit 31 of nbase: the tile's bits must
 //           be recomputed from the row arrays because the row before its first row was not at hand)
 //   pay     per tile up to BL_PAY_CAP baselines, any order: clk of the row before | bs << 32 | entry in tile << 40
@@ -118,7 +119,7 @@ struct correct_ws {
     uint32_t *srt_rb;                            // [F * bl_cap] per group: distinct clk_b mod cycle, ascending
     uint4 *srt_pay;                              // same order: (baseline index in group, clk_b div cycle, bs_b, 0)
     int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
-    uint16_t *rmask;                             // [F * row_cap / 4] per 4 entries: group-start bits | baseline bits << 4 | row bits << 8
+    uint16_t *rmask;                             // [F * row_cap / 4] per 4 entries: group-start bits | baseline bits << 4 | row bits << 8 | FLAG == 1 bits << 12
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
     static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }

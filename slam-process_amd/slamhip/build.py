@@ -35,7 +35,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def one(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("SLAM_EXTRA_FLAGS", "").split(), "-c", src, "-o", obj]     # tuning builds: -D... overrides
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

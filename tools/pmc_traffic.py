@@ -24,8 +24,11 @@ def per_kernel(path, counter):
                 continue
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             k = re.sub(r"^void |\(.*$", "", k)
-            rest = k.startswith("k_rows_finish<") and k.rstrip().endswith("false>")    # the full build, launched after the lean one
-            k = re.sub(r"<.*$", "", k).split("::")[-1] + ("_rest" if rest else "")
+            suffix = ""
+            m = re.match(r"k_rows_finish<.*?, (\d+), \d+>", k)       # lean / mid / full build of the correction kernel
+            if m:
+                suffix = {"0": "", "1": "_mid", "2": "_rest"}[m.group(1)]
+            k = re.sub(r"<.*$", "", k).split("::")[-1] + suffix
             if k.startswith("k_"):
                 acc[k[2:]].append(float(r["Counter_Value"]))
     return {k: statistics.median(v) for k, v in acc.items()}
