@@ -639,7 +639,7 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     const uint32_t row_cap = round16(n + 16);
     const int cells = n_axis * n_axis;
     ws_plan p;
-    size_t oc[3], ostat = p.add(SLAM_STAT_WORDS * 4), ob2a = p.add(64 * sizeof(int16_t)), omat = p.add((size_t)cells * 8), rw[10];
+    size_t oc[3], ostat = p.add(SLAM_STAT_WORDS * 4), ob2a = p.add(64 * sizeof(int16_t)), omat = p.add((size_t)cells * 8), rw[12];
     for (int i = 0; i < 3; i++) oc[i] = p.add((size_t)row_cap * 4);
     render_ws::plan(p, 1, 1, 1, n_axis, rw);
     SLAM_TRY(slam_ws_reserve(ctx, p.total));
@@ -659,10 +659,13 @@ extern "C" int slam_pivot_mean(slam_ctx *ctx, const int32_t *ue, const int32_t *
     rp.n_axis = n_axis;
     SLAM_TRY((pivot_accumulate<int32_t, int32_t>(ctx, (int32_t *)(b + oc[0]), (int32_t *)(b + oc[1]),
                                                  (int32_t *)(b + oc[2]), row_cap, 1, stats, SLAM_STAT_KEPT, rp, ws)));
-    SLAM_TRY(mean_only(ctx, ws.sum, ws.cnt, cells, (double *)(b + omat)));
+    // a wide table's accumulators sit on the axis grid in sum_w / cnt_w (sum / cnt then hold the beam pairs)
+    const unsigned long long *gsum = n_axis > SMALL_AXIS ? ws.sum_w : ws.sum;
+    const uint32_t *gcnt = n_axis > SMALL_AXIS ? ws.cnt_w : ws.cnt;
+    SLAM_TRY(mean_only(ctx, gsum, gcnt, cells, (double *)(b + omat)));
     std::vector<uint32_t> c32(cells);
-    if (sum) SLAM_TRY(d2h(ctx, sum, ws.sum, (size_t)cells * 8));
-    SLAM_TRY(d2h(ctx, c32.data(), ws.cnt, (size_t)cells * 4));
+    if (sum) SLAM_TRY(d2h(ctx, sum, gsum, (size_t)cells * 8));
+    SLAM_TRY(d2h(ctx, c32.data(), gcnt, (size_t)cells * 4));
     if (matrix) SLAM_TRY(d2h(ctx, matrix, b + omat, (size_t)cells * 8));
     SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (cnt) for (int i = 0; i < cells; i++) cnt[i] = c32[i];
@@ -773,7 +776,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[6], cw[16], rw[10], tc, tb[3];
+    size_t fw[6], cw[16], rw[12], tc, tb[3];
     uint32_t nt_max, st_max, bl_cap;
     size_t total;
 };

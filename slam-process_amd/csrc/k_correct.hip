@@ -476,8 +476,11 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
         }
         // in the batched path rt_nbase is free: its entry f tells k_rows_finish that frame f has a group whose phase
         // table may not fit a wave's registers (bit 0) and k_bl_sort that one is left for it to sort (bit 2)
-        if (m > WAVE_SORT_MAX && bits.pay && lane == 0)      // bit 3: a table the mid build of k_rows_finish cannot hold
+        if (m > WAVE_SORT_MAX && bits.pay && lane == 0) {    // bit 3: a table the mid build of k_rows_finish cannot hold
+            // fire and forget: a load of the word first, to skip the atomic when the bits are there, makes the wave wait
+            // for it and cost 50 % more on frames of a thousand such groups
             atomicOr(ws.rt_nbase + f, (m > MID_SORT_MAX ? 5u : 1u) | (m >= MID_TAB_CAP ? 8u : 0u));
+        }
         if (m > MID_SORT_MAX) continue;
         if (m > WAVE_SORT_MAX) {
             unsigned long long *kk = mid_keys[threadIdx.x >> 6];
@@ -1091,6 +1094,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         }
         if (!staged) return;
     }
+    uint32_t kept_wg = 0;                                // rows the workgroup kept, over all its blocks
     uint32_t in_lds_group = 0xFFFFFFFFu, P = 2;          // group whose table sits in t_rb / t_pay, its padded length
     uint32_t in_reg_group = 0xFFFFFFFFu, t_r = 0xFFFFFFFFu, t_x = 0, t_y = 0, t_z = 0;   // small table: entry `lane`
     uint32_t pv[7] = {0, 0, 0, 0, 0, 0, 0};              // its entries 7, 15, ..., 55 (wave-uniform)
@@ -1332,11 +1336,11 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
             *reinterpret_cast<V32 *>(out.rss + ob) = reinterpret_cast<const V32 *>(k_rs)[tid];
             *reinterpret_cast<V32 *>(out.clk + ob) = reinterpret_cast<const V32 *>(k_ck)[tid];
         }
-        if (tid == 0) {
-            out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
-            if (nk) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, nk);
-        }
+        if (tid == 0) out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
+        kept_wg += nk;
     }
+    // one atomic per workgroup: a long frame's kept counter is a hot word otherwise
+    if (tid == 0 && kept_wg) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, kept_wg);
 }
 
 }  // namespace

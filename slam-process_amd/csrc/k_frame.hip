@@ -650,7 +650,9 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
     __shared__ __attribute__((aligned(16))) uint32_t stage[4][STAGE_DW];
     __shared__ uint32_t prevrec[4][4];          // per wave: the record before the tile's first (clk, rss, ue | flag << 8, state)
     const uint32_t f = blockIdx.y, wv = threadIdx.x >> 6, lane = lane_id();
+    __shared__ uint32_t wave_cnt[4][2];         // per wave: records, discards (a wave that leaves early leaves zeros)
     uint32_t *st = stats + f * SLAM_STAT_WORDS;
+    if (lane == 0) { wave_cnt[wv][0] = 0; wave_cnt[wv][1] = 0; }
     if (st[SLAM_STAT_TWO_PASS]) return;
     const src_view sv = resolve_src<MODE>(src, f);
     const uint32_t nt = (sv.nb + SLOT_TILE - 1) / SLOT_TILE;
@@ -818,11 +820,16 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
         accv += cnt;
         wave_lds_sync();
     }
+    // one pair of atomics per workgroup: with thousands of workgroups per frame the frame's two counters are a hot line
     accv = wave_sum(accv);
     accd = wave_sum(accd);
-    if (lane == 0) {
-        if (accv) atomicAdd(st + SLAM_STAT_VALID, accv);
-        if (accd) atomicAdd(st + SLAM_STAT_DISCARDED, accd);
+    if (lane == 0) { wave_cnt[wv][0] = accv; wave_cnt[wv][1] = accd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tv = wave_cnt[0][0] + wave_cnt[1][0] + wave_cnt[2][0] + wave_cnt[3][0];
+        const uint32_t td = wave_cnt[0][1] + wave_cnt[1][1] + wave_cnt[2][1] + wave_cnt[3][1];
+        if (tv) atomicAdd(st + SLAM_STAT_VALID, tv);
+        if (td) atomicAdd(st + SLAM_STAT_DISCARDED, td);
     }
     if (bad & BAD_MASK) st[SLAM_STAT_NOT_STRICT] = 1;
     if (unsync) st[SLAM_STAT_TWO_PASS] = 1;

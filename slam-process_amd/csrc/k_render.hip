@@ -36,8 +36,10 @@ template <typename T8, typename T32>
 __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, const T32 *rss, uint32_t row_cap,
                                                 const uint32_t *stats, int stat_word, const int16_t *beam_to_axis,
                                                 int n_axis, uint32_t cell_stride, unsigned long long *gsum, uint32_t *gcnt,
-                                                const uint32_t *slot_cnt, uint32_t slot_stride)
+                                                const uint32_t *slot_cnt, uint32_t slot_stride, int beam_space)
 {
+    // beam_space: the global accumulators are the 64 x 64 beam pairs themselves (cell = bs * 64 + ue); the caller maps
+    // them onto a wide axis grid once per frame (k_wide_scatter) instead of every workgroup scattering over it
     // One packed accumulator per (BS beam, UE beam) pair: count at the top, sum below (see pivot_chunk).  Rows are
     // accumulated in beam space, whatever the size of the axis table; the beam -> axis mapping is applied once per
     // pair when the workgroup flushes (pairs with an unmapped beam are dropped there, map_angles :275).  Rows are
@@ -97,8 +99,9 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
                 } else {                                                             // no room in the packed sum
                     const int c = b2a[uu[k]], rw = b2a[bb[k]];
                     if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
-                    atomicAdd(&gsum[(size_t)f * cell_stride + rw * n_axis + c], (unsigned long long)rr[k]);
-                    atomicAdd(&gcnt[(size_t)f * cell_stride + rw * n_axis + c], 1u);
+                    const size_t cell = (size_t)f * cell_stride + (beam_space ? (size_t)(bb[k] * N_BEAMS + uu[k]) : (size_t)(rw * n_axis + c));
+                    atomicAdd(&gsum[cell], (unsigned long long)rr[k]);
+                    atomicAdd(&gcnt[cell], 1u);
                 }
             }
         }
@@ -111,8 +114,9 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
         // unmapped beam (-1) dropped (:275); an index at or past n_axis cannot come from a valid table
         const int c = b2a[uu], rw = b2a[bb];
         if ((uint32_t)c >= (uint32_t)n_axis || (uint32_t)rw >= (uint32_t)n_axis) continue;
-        atomicAdd(&gsum[(size_t)f * cell_stride + rw * n_axis + c], a & ((1ull << SHIFT) - 1));
-        atomicAdd(&gcnt[(size_t)f * cell_stride + rw * n_axis + c], (uint32_t)(a >> SHIFT));
+        const size_t cell = (size_t)f * cell_stride + (beam_space ? (size_t)i : (size_t)(rw * n_axis + c));
+        atomicAdd(&gsum[cell], a & ((1ull << SHIFT) - 1));
+        atomicAdd(&gcnt[cell], (uint32_t)(a >> SHIFT));
     }
 }
 
@@ -462,15 +466,30 @@ __device__ __forceinline__ double key_value(unsigned long long k)
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
 }
 
+// beam-pair accumulators (64 x 64 per frame, as the pivot leaves them for a wide table) onto the axis grid: one
+// pass per frame; beams that share an axis entry add up there
+__global__ __launch_bounds__(256) void k_wide_scatter(render_params rp, render_ws ws)
+{
+    const uint32_t f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;          // i = bs * 64 + ue
+    const uint32_t k = ws.cnt[(size_t)f * MAX_CELLS + i];
+    if (!k) return;
+    const int rw = rp.beam_to_axis[i >> 6], c = rp.beam_to_axis[i & 63];
+    if ((uint32_t)c >= (uint32_t)rp.n_axis || (uint32_t)rw >= (uint32_t)rp.n_axis) return;
+    const size_t cell = (size_t)f * ws.cell_stride + (size_t)rw * rp.n_axis + c;
+    atomicAdd(&ws.sum_w[cell], ws.sum[(size_t)f * MAX_CELLS + i]);
+    atomicAdd(&ws.cnt_w[cell], k);
+}
+
 __global__ __launch_bounds__(256) void k_wide_mean(render_params rp, render_ws ws, double *matrix)
 {
     const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     const uint32_t na = (uint32_t)rp.n_axis;
     if (c >= na * na) return;
-    const uint32_t k = ws.cnt[(size_t)f * ws.cell_stride + c];
-    const double mean = k ? (double)(long long)ws.sum[(size_t)f * ws.cell_stride + c] / (double)k
+    const uint32_t k = ws.cnt_w[(size_t)f * ws.cell_stride + c];
+    const double mean = k ? (double)(long long)ws.sum_w[(size_t)f * ws.cell_stride + c] / (double)k
                           : __longlong_as_double(0x7FF8000000000000ll);
-    ws.grid_b[(size_t)f * ws.cell_stride + c] = mean;
+    // with the full grid the compact matrix is the grid itself: it goes straight to where the blur reads
+    (rp.full_grid ? ws.grid_a : ws.grid_b)[(size_t)f * ws.cell_stride + c] = mean;
     if (matrix) matrix[(size_t)f * na * na + c] = mean;
     if (k) {                                       // every writer stores the same value
         ws.present[(size_t)f * 2 * WIDE_AXIS + c / na] = 1u;
@@ -500,8 +519,6 @@ __global__ __launch_bounds__(256) void k_wide_axes(render_params rp, render_ws w
         st[SLAM_STAT_N_AOD] = h;
         st[SLAM_STAT_N_AOA] = w;
         st[SLAM_STAT_ALLNAN] = (h == 0 || w == 0) ? 1u : 0u;
-        ws.minmax[(size_t)f * 2] = ~0ull;
-        ws.minmax[(size_t)f * 2 + 1] = 0ull;
     }
     if (h == 0 || w == 0) return;
     __syncthreads();
@@ -525,17 +542,57 @@ __global__ __launch_bounds__(256) void k_wide_compact(render_params rp, render_w
         ws.grid_b[(size_t)f * ws.cell_stride + (uint32_t)ridx[c / w] * (uint32_t)rp.n_axis + (uint32_t)cidx[c % w]];
 }
 
-// blur (or copy, ks <= 1) of the compact matrix, the finite minimum / maximum of the result
+// blur (or copy, ks <= 1) of the compact matrix, the finite minimum / maximum of the result.  A workgroup owns a
+// 16 x 16 piece of the matrix; for kernels of up to WIDE_BLUR_KS taps a side it stages the piece with its halo (edge
+// padding applied) and the weights in LDS and sums the taps in the same order as blur_cell.
+constexpr int WIDE_BLUR_KS = 15, WIDE_BLUR_T = 16, WIDE_BLUR_TW = WIDE_BLUR_T + WIDE_BLUR_KS - 1;
+constexpr int WIDE_BLUR_SLOTS = (WIDE_AXIS / WIDE_BLUR_T) * (WIDE_AXIS / WIDE_BLUR_T);       // pieces per frame at most
 __global__ __launch_bounds__(256) void k_wide_blur(render_params rp, render_ws ws, const double *kern, int ks,
                                                     double *blurred, const uint32_t *stats)
 {
-    const uint32_t f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t h = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOD], w = stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOA];
-    if (blockIdx.x * 256 >= h * w) return;                          // whole workgroup past the matrix
+    __shared__ double tile[WIDE_BLUR_TW * WIDE_BLUR_TW];
+    __shared__ double wgt[WIDE_BLUR_KS * WIDE_BLUR_KS];
+    const uint32_t f = blockIdx.z;
+    const int h = (int)stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOD], w = (int)stats[f * SLAM_STAT_WORDS + SLAM_STAT_N_AOA];
+    __shared__ unsigned long long part[4][2];
+    const int i0 = blockIdx.y * WIDE_BLUR_T, j0 = blockIdx.x * WIDE_BLUR_T;
+    // every workgroup leaves the minimum / maximum of its piece (keys; none: ~0, 0) in its own slot: no atomics on a
+    // word the whole frame shares
+    unsigned long long *slot = ws.minmax + ((size_t)f * WIDE_BLUR_SLOTS + blockIdx.y * gridDim.x + blockIdx.x) * 2;
+    if (i0 >= h || j0 >= w) {                                       // whole workgroup past the matrix
+        if (threadIdx.x == 0) { slot[0] = ~0ull; slot[1] = 0ull; }
+        return;
+    }
     const double *in = ws.grid_a + (size_t)f * ws.cell_stride;
+    const int li = threadIdx.x / WIDE_BLUR_T, lj = threadIdx.x % WIDE_BLUR_T, i = i0 + li, j = j0 + lj;
+    const bool mine = i < h && j < w;
+    const int c = i * w + j;
+    double v = 0.0;
+    if (ks > 1 && ks <= WIDE_BLUR_KS) {
+        const int p = ks / 2, tw = WIDE_BLUR_T + ks - 1;
+        for (int t = threadIdx.x; t < tw * tw; t += 256) {
+            int ii = i0 - p + t / tw, jj = j0 - p + t % tw;
+            ii = ii < 0 ? 0 : (ii >= h ? h - 1 : ii);
+            jj = jj < 0 ? 0 : (jj >= w ? w - 1 : jj);
+            tile[t] = in[ii * w + jj];
+        }
+        for (int t = threadIdx.x; t < ks * ks; t += 256) wgt[t] = kern[t];
+        __syncthreads();
+        double num = 0.0, den = 0.0;
+        for (int a = 0; a < ks; a++)
+            for (int b = 0; b < ks; b++) {
+                const double x = tile[(li + a) * tw + lj + b];
+                const bool fin = finite_d(x);
+                const double wt = wgt[a * ks + b] * (fin ? 1.0 : 0.0);
+                num += (fin ? x : 0.0) * wt;
+                den += wt;
+            }
+        v = den > 1e-12 ? num / den : __longlong_as_double(0x7FF8000000000000ll);
+    } else if (mine) {
+        v = ks > 1 ? blur_cell(in, h, w, kern, ks, c) : in[c];
+    }
     unsigned long long lo = ~0ull, hi = 0ull;
-    if (c < h * w) {
-        const double v = ks > 1 ? blur_cell(in, (int)h, (int)w, kern, ks, (int)c) : in[c];
+    if (mine) {
         ws.grid_b[(size_t)f * ws.cell_stride + c] = v;
         if (blurred) blurred[(size_t)f * rp.n_axis * rp.n_axis + c] = v;
         if (finite_d(v)) lo = hi = order_key(v);
@@ -546,9 +603,15 @@ __global__ __launch_bounds__(256) void k_wide_blur(render_params rp, render_ws w
         lo = ol < lo ? ol : lo;
         hi = oh > hi ? oh : hi;
     }
-    if (lane_id() == 0 && lo <= hi) {
-        atomicMin(ws.minmax + (size_t)f * 2, lo);
-        atomicMax(ws.minmax + (size_t)f * 2 + 1, hi);
+    if (lane_id() == 0) { part[threadIdx.x >> 6][0] = lo; part[threadIdx.x >> 6][1] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) {
+            lo = part[k][0] < lo ? part[k][0] : lo;
+            hi = part[k][1] > hi ? part[k][1] : hi;
+        }
+        slot[0] = lo;
+        slot[1] = hi;
     }
 }
 
@@ -559,7 +622,26 @@ __global__ __launch_bounds__(256) void k_wide_colour(render_params rp, render_ws
     const uint32_t h = st[SLAM_STAT_N_AOD], w = st[SLAM_STAT_N_AOA];
     if (h == 0 || w == 0) return;
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
-    const unsigned long long klo = ws.minmax[(size_t)f * 2], khi = ws.minmax[(size_t)f * 2 + 1];
+    // the frame's minimum / maximum out of the blur's per-piece slots (every workgroup reduces them for itself)
+    __shared__ unsigned long long red[4][2];
+    const uint32_t bt = ((uint32_t)rp.n_axis + WIDE_BLUR_T - 1) / WIDE_BLUR_T, nslot = bt * bt;
+    unsigned long long klo = ~0ull, khi = 0ull;
+    if (threadIdx.x < nslot) {
+        klo = ws.minmax[((size_t)f * WIDE_BLUR_SLOTS + threadIdx.x) * 2];
+        khi = ws.minmax[((size_t)f * WIDE_BLUR_SLOTS + threadIdx.x) * 2 + 1];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long ol = shfl64(klo, (int)(lane_id() ^ d)), oh = shfl64(khi, (int)(lane_id() ^ d));
+        klo = ol < klo ? ol : klo;
+        khi = oh > khi ? oh : khi;
+    }
+    if (lane_id() == 0) { red[threadIdx.x >> 6][0] = klo; red[threadIdx.x >> 6][1] = khi; }
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        klo = red[k][0] < klo ? red[k][0] : klo;
+        khi = red[k][1] > khi ? red[k][1] : khi;
+    }
     if (klo > khi) {                                               // no finite cell
         if (first) st[SLAM_STAT_ALLNAN] = 1;
         return;
@@ -632,12 +714,12 @@ extern "C" uint32_t slam_cells_per_frame(int32_t n_axis)
     return n_axis <= SMALL_AXIS ? (uint32_t)MAX_CELLS : (uint32_t)n_axis * (uint32_t)n_axis;
 }
 
-void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[10])
+void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[12])
 {
     const size_t cells = slam_cells_per_frame(n_axis);
     const bool wide = n_axis > SMALL_AXIS;
-    off[0] = p.add((size_t)F * cells * 8);
-    off[1] = p.add((size_t)F * cells * 4);
+    off[0] = p.add((size_t)F * (wide ? MAX_CELLS : cells) * 8);      // a wide table: beam pairs here, the axis grid in sum_w
+    off[1] = p.add((size_t)F * (wide ? MAX_CELLS : cells) * 4);
     off[2] = p.add((size_t)F * cells * 4);
     off[3] = p.add((size_t)F * (size_t)(W > 0 ? W : 1) * 2);
     off[4] = p.add((size_t)F * (size_t)(H > 0 ? H : 1) * 2);
@@ -645,10 +727,12 @@ void render_ws::plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t of
     off[6] = p.add(wide ? (size_t)F * cells * 8 : 0);
     off[7] = p.add(wide ? (size_t)F * 2 * WIDE_AXIS * 4 : 0);
     off[8] = p.add(wide ? (size_t)F * 2 * WIDE_AXIS * 2 : 0);
-    off[9] = p.add(wide ? (size_t)F * 2 * 8 : 0);
+    off[9] = p.add(wide ? (size_t)F * 2 * 8 * 256 : 0);            // a minimum / maximum slot per 16 x 16 piece
+    off[10] = p.add(wide ? (size_t)F * cells * 8 : 0);
+    off[11] = p.add(wide ? (size_t)F * cells * 4 : 0);
 }
 
-void render_ws::bind(uint8_t *base, const size_t off[10], int n_axis)
+void render_ws::bind(uint8_t *base, const size_t off[12], int n_axis)
 {
     sum = (unsigned long long *)(base + off[0]);
     cnt = (uint32_t *)(base + off[1]);
@@ -660,6 +744,8 @@ void render_ws::bind(uint8_t *base, const size_t off[10], int n_axis)
     present = (uint32_t *)(base + off[7]);
     axis_idx = (int16_t *)(base + off[8]);
     minmax = (unsigned long long *)(base + off[9]);
+    sum_w = (unsigned long long *)(base + off[10]);
+    cnt_w = (uint32_t *)(base + off[11]);
     cell_stride = slam_cells_per_frame(n_axis);
 }
 
@@ -670,12 +756,19 @@ int pivot_accumulate(slam_ctx *ctx, const T8 *ue, const T8 *bs, const T32 *rss, 
 {
     if (F == 0) return SLAM_OK;
     if (rp.n_axis < 1 || rp.n_axis > WIDE_AXIS) return slam_fail(ctx, SLAM_E_INVALID, "n_axis must be 1..%d", WIDE_AXIS);
-    SLAM_TRY(slam_zero_async(ctx, ws.sum, (size_t)F * ws.cell_stride * 8));
-    SLAM_TRY(slam_zero_async(ctx, ws.cnt, (size_t)F * ws.cell_stride * 4));
+    const bool wide = rp.n_axis > SMALL_AXIS;
+    const uint32_t stride = wide ? (uint32_t)MAX_CELLS : ws.cell_stride;
+    SLAM_TRY(slam_zero_async(ctx, ws.sum, (size_t)F * stride * 8));
+    SLAM_TRY(slam_zero_async(ctx, ws.cnt, (size_t)F * stride * 4));
     constexpr uint32_t chunk = 1u << pivot_chunk<T32>::log2;
     dim3 grid((row_cap + chunk - 1) / chunk, F), block(1024);
     SLAM_LAUNCH(ctx, "pivot", (k_pivot<T8, T32>), grid, block, ue, bs, rss, row_cap, stats, stat_word,
-                rp.beam_to_axis, rp.n_axis, ws.cell_stride, ws.sum, ws.cnt, slot_cnt, slot_stride);
+                rp.beam_to_axis, rp.n_axis, stride, ws.sum, ws.cnt, slot_cnt, slot_stride, wide ? 1 : 0);
+    if (wide) {          // beam pairs -> axis grid, once per frame
+        SLAM_TRY(slam_zero_async(ctx, ws.sum_w, (size_t)F * ws.cell_stride * 8));
+        SLAM_TRY(slam_zero_async(ctx, ws.cnt_w, (size_t)F * ws.cell_stride * 4));
+        SLAM_LAUNCH(ctx, "wide_scatter", k_wide_scatter, dim3(MAX_CELLS / 256, F), dim3(256), rp, ws);
+    }
     return SLAM_OK;
 }
 
@@ -721,8 +814,9 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
         if (!rp.full_grid) SLAM_TRY(slam_zero_async(ctx, ws.present, (size_t)F * 2 * WIDE_AXIS * 4));
         SLAM_LAUNCH(ctx, "wide_mean", k_wide_mean, cgrid, blk, rp, ws, matrix);
         SLAM_LAUNCH(ctx, "wide_axes", k_wide_axes, dim3(F), blk, rp, ws, stats);
-        SLAM_LAUNCH(ctx, "wide_compact", k_wide_compact, cgrid, blk, rp, ws, stats);
-        SLAM_LAUNCH(ctx, "wide_blur", k_wide_blur, cgrid, blk, rp, ws, kern, ks, blurred, stats);
+        if (!rp.full_grid) SLAM_LAUNCH(ctx, "wide_compact", k_wide_compact, cgrid, blk, rp, ws, stats);
+        const uint32_t bt = (uint32_t)(rp.n_axis + WIDE_BLUR_T - 1) / WIDE_BLUR_T;
+        SLAM_LAUNCH(ctx, "wide_blur", k_wide_blur, dim3(bt, bt, F), blk, rp, ws, kern, ks, blurred, stats);
         SLAM_LAUNCH(ctx, "wide_colour", k_wide_colour, cgrid, blk, rp, ws, stats);
     }
     if (tile)

@@ -159,7 +159,7 @@ struct render_params {
 };
 
 struct render_ws {
-    unsigned long long *sum;        // [F * cells]   cells = slam_cells_per_frame(n_axis)
+    unsigned long long *sum;        // [F * cells]   cells = slam_cells_per_frame(n_axis) (wide tables: [F * 4096] beam pairs)
     uint32_t *cnt;                  // [F * cells]
     uint8_t *cells;                 // [F * cells * 4] RGBA per compact cell
     int16_t *colmap, *rowmap;       // [F * W], [F * H] pixel -> compact cell index
@@ -167,10 +167,12 @@ struct render_ws {
     double *grid_a, *grid_b;        // [F * cells] full-grid mean / compact mean / blurred, in turn
     uint32_t *present;              // [F * 2 * WIDE_AXIS] rows, then columns, that hold data
     int16_t *axis_idx;              // [F * 2 * WIDE_AXIS] compact row -> axis entry, compact column -> axis entry
-    unsigned long long *minmax;     // [F * 2] order-preserving keys of the finite minimum / maximum
+    unsigned long long *minmax;     // [F * 256 * 2] per 16 x 16 piece: order-preserving keys of its finite minimum / maximum
+    unsigned long long *sum_w;      // [F * cells] sums / counts on the axis grid (sum / cnt then hold the 64 x 64 beam pairs)
+    uint32_t *cnt_w;
     uint32_t cell_stride;           // cells per frame
-    static void plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[10]);
-    void bind(uint8_t *base, const size_t off[10], int n_axis);
+    static void plan(ws_plan &p, uint32_t F, int W, int H, int n_axis, size_t off[12]);
+    void bind(uint8_t *base, const size_t off[12], int n_axis);
 };
 
 // slot_cnt != nullptr: the rows are slotted per ROWS_PER_BLOCK entries (kept_out_t) and stat_word counts entries
