@@ -11,8 +11,11 @@ for path in sys.argv[1:]:
         for r in csv.DictReader(fh):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             k = re.sub(r"^void |\(.*$", "", k)
-            rest = k.startswith("k_rows_finish<") and k.rstrip().endswith("false>")    # the full build, launched after the lean one
-            k = re.sub(r"<.*$", "", k).split("::")[-1] + ("_rest" if rest else "")
+            suffix = ""
+            m = re.match(r"k_rows_finish<.*?, (\d+), \d+>", k)       # lean / mid / full build of the correction kernel
+            if m:
+                suffix = {"0": "", "1": "_mid", "2": "_rest"}[m.group(1)]
+            k = re.sub(r"<.*$", "", k).split("::")[-1] + suffix
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel," + ",".join(names))
