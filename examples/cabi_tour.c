@@ -129,6 +129,25 @@ int main(void)
     b2a[9] = 3;
     CHECK(slam_pivot_mean(ctx, pue, pbs, prs, 6, b2a, 3, sum, cnt, mat) == SLAM_E_INVALID);
     b2a[9] = -1;
+    /* RSS values that are not whole numbers: per cell the compensated sum in row order, as pandas' pivot mean.
+     * 1e16 + 1 + 1 - 1e16: a plain left-to-right sum loses both ones (0), the compensated one keeps them (2) */
+    const int32_t fue[7] = {0, 0, 0, 0, 2, 2, 5}, fbs[7] = {2, 2, 2, 2, 3, 3, 2};
+    const double frs[7] = {1e16, 1.0, 1.0, -1e16, -70.25, NAN, 3.0};
+    double fsum[9];
+    CHECK(slam_pivot_mean_f64(ctx, fue, fbs, frs, 7, b2a, 3, fsum, cnt, mat) == SLAM_OK);
+    CHECK(cnt[1 * 3 + 0] == 4 && fsum[1 * 3 + 0] == 2.0 && mat[1 * 3 + 0] == 0.5);
+    CHECK(cnt[2 * 3 + 1] == 1 && mat[2 * 3 + 1] == -70.25 && isnan(mat[0]));                  /* the NaN value is not counted */
+    /* an axis table of 256 entries (the up-scaled beam table): cells per frame of the batched buffers */
+    CHECK(slam_cells_per_frame(64) == 4096 && slam_cells_per_frame(65) == 65 * 65 && slam_cells_per_frame(256) == 65536);
+    /* a pinned workspace refuses to grow: a call that needs more than is reserved fails instead of reallocating */
+    CHECK(slam_pin_workspace(ctx, 1) == SLAM_OK);
+    {
+        static double big[600 * 600], bigo[600 * 600];
+        for (int i = 0; i < 600 * 600; i++) big[i] = 1.0;
+        CHECK(slam_blur_nan(ctx, big, 600, 600, 1.0, bigo) == SLAM_E_CAPACITY);
+        CHECK(slam_pin_workspace(ctx, 0) == SLAM_OK);
+        CHECK(slam_blur_nan(ctx, big, 600, 600, 1.0, bigo) == SLAM_OK && fabs(bigo[300 * 600 + 300] - 1.0) < 1e-12);
+    }
 
     /* ---- a11 - a12: blur.  A constant stays constant, NaN cells are filled from their neighbours, sigma <= 0 copies */
     double m[12], bl[12];

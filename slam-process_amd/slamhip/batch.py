@@ -16,16 +16,48 @@ from . import _lib, ops
 from .pipeline import FramePipeline, STAGE_ALL
 
 
+# Buffers and pipelines of the default configuration are kept between calls (a pipeline owns a few hundred MB of device
+# arrays and a library workspace: building one per call costs more than processing nineteen captures).
+_CACHE: Dict[tuple, object] = {}
+_CACHE_MAX = 6
+
+
+def _cached(key, make):
+    v = _CACHE.get(key)
+    if v is None:
+        while len(_CACHE) >= _CACHE_MAX:
+            _CACHE.pop(next(iter(_CACHE)))
+        v = _CACHE[key] = make()
+    return v
+
+
 def _pack(chunks: Sequence[np.ndarray], device) -> tuple:
+    """The chunks at 256-byte aligned offsets of one device buffer (staged through pinned host memory)."""
     offs, lens, pos = [], [], 0
     for c in chunks:
         offs.append(pos)
         lens.append(len(c))
         pos += (len(c) + 255) // 256 * 256
-    buf = np.zeros(pos + 256, np.uint8)
+    cap = max(1 << 20, 1 << (pos + 256 - 1).bit_length())                 # buffers by power-of-two size class
+    host = _cached(("pin", cap), lambda: torch.empty(cap, dtype=torch.uint8, pin_memory=True))
+    dev = _cached(("dev", str(device), cap), lambda: torch.empty(cap, dtype=torch.uint8, device=device))
+    hv = host.numpy()
     for o, c in zip(offs, chunks):
-        buf[o:o + len(c)] = c
-    return torch.from_numpy(buf).to(device), offs, lens
+        hv[o:o + len(c)] = c
+        hv[o + len(c):(o + len(c) + 255) // 256 * 256 + 32] = 0           # the slack the kernels may read past a frame
+    dev[:pos + 256].copy_(host[:pos + 256], non_blocking=True)
+    return dev, offs, lens
+
+
+def _pipeline(n: int, max_len: int, device: int, tile: int, src_is_bytes: bool, kwargs: dict) -> FramePipeline:
+    """A pipeline that holds n frames of up to max_len bytes; with default settings, one kept from an earlier call
+    whose capacity suffices."""
+    if kwargs:
+        return FramePipeline(n, max(max_len, 1), device=device, tile_w=tile, tile_h=tile, src_is_bytes=src_is_bytes, **kwargs)
+    n_cap = max(8, 1 << (n - 1).bit_length())
+    len_cap = max(1 << 20, 1 << (max(max_len, 1) - 1).bit_length())
+    return _cached(("pipe", device, n_cap, len_cap, tile, src_is_bytes),
+                   lambda: FramePipeline(n_cap, len_cap, device=device, tile_w=tile, tile_h=tile, src_is_bytes=src_is_bytes))
 
 
 def _collect(pipe: FramePipeline, n: int, rows: bool, tiles: str) -> List[Dict]:
@@ -38,8 +70,8 @@ def _collect(pipe: FramePipeline, n: int, rows: bool, tiles: str) -> List[Dict]:
             r.update(rows=pipe.frame_rows(f, st), kept=pipe.frame_kept(f, st))
         if tiles == "host":
             r["tile"] = pipe.frame_tile(f)
-        else:                       # a view of the pipeline's tile buffer: stays on the device (e.g. for a gather)
-            r["tile_dev"] = pipe.tiles[f]
+        else:                       # stays on the device (e.g. for a gather); a copy: the pipeline's buffer is reused
+            r["tile_dev"] = pipe.tiles[f].clone()
         out.append(r)
     return out
 
@@ -56,7 +88,7 @@ def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, row
     dev = torch.device("cuda", device)
     arrs = [np.frombuffer(bytes(t), np.uint8) for t in texts]
     buf, offs, lens = _pack(arrs, dev)
-    pipe = FramePipeline(len(arrs), max(max(lens), 1), device=device, tile_w=tile, tile_h=tile, **pipeline_kwargs)
+    pipe = _pipeline(len(arrs), max(lens), device, tile, False, pipeline_kwargs)
     pipe.set_layout(offs, lens)
     pipe.run(buf, stages=STAGE_ALL)
     res = _collect(pipe, len(arrs), rows, tiles)
@@ -64,8 +96,7 @@ def process_texts(texts: Sequence[bytes], device: int = 0, tile: int = 1024, row
     if loose:
         data = [ops.hex_unpack(arrs[i], device=device) for i in loose]
         bbuf, boffs, blens = _pack(data, dev)
-        bpipe = FramePipeline(len(data), max(max(blens), 1), device=device, tile_w=tile, tile_h=tile,
-                              src_is_bytes=True, **pipeline_kwargs)
+        bpipe = _pipeline(len(data), max(blens), device, tile, True, pipeline_kwargs)
         bpipe.set_layout(boffs, blens)
         bpipe.run(bbuf, stages=STAGE_ALL)
         for i, r in zip(loose, _collect(bpipe, len(data), rows, tiles)):

@@ -260,3 +260,48 @@ def test_parser_refuses_values_that_are_not_bytes():
     for bad in ([0x33, 307], [-205, 1], [0.5, 1]):
         with pytest.raises(ValueError, match="0..255"):
             S._parse_groups(bad, logging.getLogger("t"))
+
+
+def test_upscaled_axis_table_matches_the_oracles_definition():
+    """The up-scaled beam table (host logic, no GPU): the product's table and beam positions equal the oracle's
+    restatement for several factors and for sparse mappings; the table's own angles sit at every factor-th entry."""
+    from oracle import slam_oracle as O
+    from slamhip import _lib, ops
+    from slamhip.pipeline import default_mapping
+    maps = [default_mapping(), {3: 1.5}, {i: float(i // 2) for i in range(64) if i % 7}, {5: -1.0, 9: 4.0, 70: 9.0}]
+    for mp in maps:
+        b2a1, ang1 = ops.axis_from_mapping(mp)
+        for factor in (1, 2, 3, 4):
+            if len(ang1) * factor > _lib.MAX_AXIS:
+                continue
+            b2a, ang = ops.upscaled_axis(mp, factor)
+            ob2a, oang = O.upscaled_axis(mp, factor)
+            assert b2a.dtype == np.int16 and np.array_equal(b2a, ob2a) and np.array_equal(ang, oang)
+            assert np.array_equal(ang[::factor], ang1) and len(ang) == factor * len(ang1)
+            assert np.all(np.diff(ang) > 0) and np.array_equal(b2a[b2a1 >= 0], b2a1[b2a1 >= 0] * factor)
+    with pytest.raises(ValueError):
+        ops.upscaled_axis(default_mapping(), 5)              # 320 entries: beyond the library's 256
+    assert _lib.cells_per_frame(64) == 4096 and _lib.cells_per_frame(65) == 4225 and _lib.cells_per_frame(256) == 65536
+    assert _lib.load().slam_cells_per_frame(256) == 65536 and _lib.load().slam_cells_per_frame(8) == 4096
+
+
+def test_bench_kernel_accounting_groups_the_builds_and_never_exceeds_the_peak():
+    """bench.py's per-kernel table (host logic): the builds of the correction kernel are priced together against one
+    set of algorithmic bytes, a launch too short for its nominal bytes gets no rate, the roofline entry names the
+    traffic file of the shape that ran or says that there is none."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nbytes, valid, kept, tile_bytes, F, K = 11.5e6, 1.05e6, 0.63e6, 4194304, 200, 5
+    kern = {"frame_onepass": (K, 40.0), "rows_finish": (K, 0.3), "rows_finish_mid": (K, 16.0), "rows_finish_rest": (K, 0.3),
+            "pivot": (K, 3.5), "raster": (K, 0.0005), "bl_sort_small": (K, 1.5)}
+    table, roof, ach = bench.kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / launches, 256, 16384, 1)
+    assert "rows_finish_mid" not in table and set(table["rows_finish"]["parts_avg_ms"]) == {"rows_finish", "rows_finish_mid", "rows_finish_rest"}
+    assert abs(table["rows_finish"]["avg_ms"] - (0.3 + 16.0 + 0.3) / K) < 1e-4
+    want = (10.0 * valid + 10.0 * kept) * F / ((16.6 / K) * 1e-3) / 1e9
+    assert abs(table["rows_finish"]["alg_GBps"] - want) < 1.0
+    assert table["raster"]["alg_GBps"] is None and "alg_note" in table["raster"]          # would be far above the peak
+    assert all(v.get("alg_GBps") is None or v["alg_GBps"] <= bench.HBM_PEAK_GBS for v in table.values())
+    assert roof["kernel"] == "frame_onepass" and roof["peak"] == 8000.0 and roof["frac"] == round(roof["achieved"] / 8000.0, 4)
+    assert roof["traffic"] is None and "256x16384" in roof["traffic_source"]
+    _t, roof2, _a = bench.kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: 800 * K / launches, 256, 4096, 1)
+    assert roof2["traffic"] and roof2["traffic_source"].startswith("profiles/")

@@ -71,7 +71,7 @@ def main():
                logs=len(texts), text_MB=round(nbytes / 1e6, 3), tile=a.tile, repeat=a.repeat,
                end_to_end=dict(seconds_per_batch=round(end_to_end, 5), logs_per_s=round(len(texts) / end_to_end, 1),
                                text_MB_per_s=round(nbytes / 1e6 / end_to_end, 1),
-                               includes="host packing, host-to-device copy, pipeline construction, the batched call, "
+                               includes="host packing into pinned memory, host-to-device copy, the batched call on a pipeline kept from the first call, "
                                         "read-back of stats and matrices; rows not fetched, tiles left on the device"),
                device_call=dict(seconds_per_batch=round(device_only, 6), logs_per_s=round(len(texts) / device_only, 1),
                                 text_GB_per_s=round(nbytes / 1e9 / device_only, 2),
