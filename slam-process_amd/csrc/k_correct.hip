@@ -1360,6 +1360,7 @@ void correct_ws::plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap,
     off[12] = p.add((size_t)F * bl_cap * 4);
     off[13] = p.add((size_t)F * bl_cap * 4);
     off[14] = p.add((size_t)F * row_cap / 2 + 16);
+    off[15] = p.add((size_t)F * rt_max * 4);
 }
 
 void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
@@ -1379,6 +1380,7 @@ void correct_ws::bind(uint8_t *base, const size_t off[16], uint32_t bl_cap_)
     tmp_a = (uint32_t *)(base + off[12]);
     tmp_b = (uint32_t *)(base + off[13]);
     rmask = (uint16_t *)(base + off[14]);
+    defer = (uint32_t *)(base + off[15]);
     bl_cap = bl_cap_;
 }
 
@@ -1434,7 +1436,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), w2, in.row_cap, prm, stats,
                     in.bits, MID_SORT_MAX);
         // the lean build first; what it defers (large groups, a tolerance of half a cycle or more) goes to the full one
-        uint32_t *defer = prm_k.small_tol ? ws.rt_nkept : nullptr;
+        // (an array of its own: rt_nkept holds the kept-row counts when the caller leaves kept_cnt_dev to the workspace)
+        uint32_t *defer = prm_k.small_tol ? ws.defer : nullptr;
         const uint32_t wgs = (rt_max + FIN_TPB - 1) / FIN_TPB, wgs_full = (rt_max + FIN_TPB_FULL - 1) / FIN_TPB_FULL;
         if (defer) {
             SLAM_LAUNCH(ctx, "rows_finish", (k_rows_finish<T8, T32, FIN_LEAN, FIN_TPB>), dim3(wgs, F), block, in, rt_max,

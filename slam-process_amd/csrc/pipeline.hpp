@@ -121,6 +121,7 @@ struct correct_ws {
     int32_t *corr;                               // [F * row_cap] corrected BS per row or "none"
     uint16_t *rmask;                             // [F * row_cap / 4] per 4 entries: group-start bits | baseline bits << 4 | row bits << 8 | FLAG == 1 bits << 12
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
+    uint32_t *defer;                             // [F * rt_max] workgroups of k_rows_finish left to its full build
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
     static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }
     static void plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap, size_t off[16]);

@@ -619,7 +619,12 @@ def test_batched_correction_mixed_frames_in_one_batch(mapping, lut):
     tiny = _wrap_stream(cycle, 21, groups=900, rows_per_group=3, n_baselines=1)
     streams = [_wrap_stream(cycle, 5), _wrap_stream(cycle, 6, groups=2, rows_per_group=400, n_baselines=100), b"",
                _wrap_stream(cycle, 7, groups=2, rows_per_group=1000, n_baselines=300), tiny, _wrap_stream(cycle, 8),
-               _wrap_stream(cycle, 9, groups=1, rows_per_group=4000, n_baselines=1500), _wrap_stream(cycle, 10)]
+               _wrap_stream(cycle, 9, groups=1, rows_per_group=4000, n_baselines=1500), _wrap_stream(cycle, 10),
+               # one frame, both kinds: mid-sized tables next to stretches of tiny groups (workgroups of the mid build
+               # defer to the full one), and a table beyond the mid build's room next to them (the full build alone)
+               _wrap_stream(cycle, 12, groups=2, rows_per_group=1200, n_baselines=200) + tiny +
+               _wrap_stream(cycle, 13, groups=3, rows_per_group=500, n_baselines=70),
+               tiny + _wrap_stream(cycle, 14, groups=1, rows_per_group=3000, n_baselines=700) + tiny]
     offs, lens, blob = [], [], bytearray()
     for sbytes in streams:
         while len(blob) % 16:
@@ -1400,3 +1405,30 @@ def test_float_rss_pivot_follows_pandas(ops, mapping):
         s, c, m = ops.pivot_mean_f64(ue, bs, rss, b2a, len(angles))
         so, co = O.pivot_mean_float(ue, bs, rss, mp)[3:]
         assert np.array_equal(c, co) and np.array_equal(s.view(np.uint64), so.view(np.uint64)), trial
+
+
+def test_batched_call_with_counts_left_to_the_workspace(mapping, lut):
+    """tile_cnt_dev, kept_cnt_dev and the cell / map buffers are optional: left NULL they live in the ctx workspace.
+    Counters, matrices and tiles are those of a run with caller-owned buffers (the per-block kept counts must not share
+    their array with anything the correction kernels write)."""
+    import ctypes as C
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 32, 2048, 3
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=17)
+    ref = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+    ref.set_uniform_layout(F, stride, tl)
+    ref.run(text)
+    st_ref = ref.stats_host().copy()
+    pipe = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.bt.tile_cnt_dev = None
+    pipe.bt.kept_cnt_dev = None
+    pipe.bt.cells_dev = pipe.bt.colmap_dev = pipe.bt.rowmap_dev = None
+    pipe.run(text)
+    assert np.array_equal(pipe.stats_host(), st_ref) and int(st_ref[:, 6].min()) > 1000
+    assert torch.equal(pipe.tiles[:F], ref.tiles[:F]) and torch.equal(pipe.matrix.view(torch.int64), ref.matrix.view(torch.int64))
+    assert torch.equal(pipe.blurred.view(torch.int64), ref.blurred.view(torch.int64))
