@@ -17,8 +17,14 @@ namespace {
 // bits at the top) over the sum, so the larger the chunk the smaller the values it can take: 2^16 entries leave
 // room for any non-negative int32, 2^18 for values below 2^27 (the capture format's RSS has 18 bits).  Values
 // outside the room bypass the accumulator.  Fewer, larger chunks mean fewer flushes of 4096 cells each.
+#ifndef SLAM_PIVOT_LOG2
+#define SLAM_PIVOT_LOG2 18
+#endif
+#ifndef SLAM_PIVOT_NH
+#define SLAM_PIVOT_NH 4
+#endif
 template <typename T32> struct pivot_chunk { static constexpr int log2 = 16; };
-template <> struct pivot_chunk<uint32_t> { static constexpr int log2 = 18; };
+template <> struct pivot_chunk<uint32_t> { static constexpr int log2 = SLAM_PIVOT_LOG2; };
 constexpr int MAX_AXIS = SMALL_AXIS;                 // the LDS-resident path: at most 64 x 64 cells
 constexpr int MAX_CELLS = MAX_AXIS * MAX_AXIS;
 constexpr int N_BEAMS = 64;                          // beam ids are 6 bit (validate_beam_id, excel_heatmap_v3.py:68-72)
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
     // padded to 65 entries: consecutive BS beams at one UE beam would otherwise put a whole wave on one LDS bank.
     constexpr int CHUNK_LOG2 = pivot_chunk<T32>::log2, PIVOT_CHUNK = 1 << CHUNK_LOG2, SHIFT = 63 - CHUNK_LOG2;
     constexpr int64_t ROW_LIMIT = 1ll << (SHIFT - CHUNK_LOG2);
-    constexpr int NH = 4;                  // groups of four entries per thread and step
+    constexpr int NH = SLAM_PIVOT_NH;      // groups of four entries per thread and step
     static_assert(PIVOT_CHUNK % (4096 * NH) == 0, "a step covers 4096 * NH entries");
     constexpr int LSTRIDE = N_BEAMS + 1;
     __shared__ unsigned long long acc[N_BEAMS * LSTRIDE];

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+LIB_PATH = os.environ.get("SLAMHIP_LIB") or os.path.join(_HERE, "libslamhip.so")     # override: tuning builds kept beside the shipped one
 
 OK, E_INVALID, E_HIP, E_CAPACITY, E_EMPTY, E_ALLNAN, E_RANGE, E_LIMITS = 0, -1, -2, -3, -4, -5, -6, -7
 STAT_WORDS = 16

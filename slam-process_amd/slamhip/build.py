@@ -8,8 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-OUT = os.path.join(HERE, "libslamhip.so")
-OBJ = os.path.join(CSRC, "_obj")
+OUT = os.environ.get("SLAMHIP_OUT") or os.path.join(HERE, "libslamhip.so")     # tuning builds: another output name ...
+OBJ = os.environ.get("SLAMHIP_OBJ") or os.path.join(CSRC, "_obj")              # ... and object directory
 # -ffp-contract=off: the f64 mean / blur / scale steps must round like NumPy, one operation at a time
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
