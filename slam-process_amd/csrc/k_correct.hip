@@ -991,7 +991,12 @@ __global__ __launch_bounds__(256) void k_rows_emit_kept(rows_in_t<T8, T32> in, u
 // group ids come from the bits k_rows_summarize left per 4 entries, the four rows of a thread search their
 // group's LDS-staged phase table in lock step (fixed trip count over the table padded to a power of two), and a
 // kept row goes straight to the front of its block's entries.
-constexpr int FIN_TPB = 3;            // consecutive blocks of entries one workgroup of k_rows_finish walks (lean build)
+#ifndef SLAM_FIN_TPB
+#define SLAM_FIN_TPB 3
+#endif
+// consecutive blocks of entries one workgroup of k_rows_finish walks (lean, mid build): 2 / 3 / 4 measured 2.95 / 2.93 / 3.17 ms
+// per 800 frames after the flag column went; asking the compiler for seven waves per SIMD instead of six: 3.25 ms
+constexpr int FIN_TPB = SLAM_FIN_TPB;
 #ifndef SLAM_FIN_TPB_FULL
 #define SLAM_FIN_TPB_FULL 3
 #endif
