@@ -7,7 +7,10 @@ constexpr int FRAME_RUN = 48;                    // data bytes owned by one lane
 constexpr int FRAME_TILE = 64 * FRAME_RUN;       // 3072 data bytes per wave tile
 constexpr int FRAME_TILE_DW = FRAME_TILE / 4 + 4;  // tile + 16 halo bytes, in dwords
 constexpr int FRAME_SUMM_WORDS = 11;             // one packed word per entry offset 0..10
-constexpr int FRAME_TPW = 4;                     // tiles each wave walks per launch
+#ifndef SLAM_FRAME_TPW
+#define SLAM_FRAME_TPW 4
+#endif
+constexpr int FRAME_TPW = SLAM_FRAME_TPW;        // tiles each wave walks per launch (2 / 3 / 4 / 8: 7.86 / 7.85 / 7.64 / 7.74 ms per 800 frames)
 // single-pass framing: a wave's tile is one look-behind run + 63 runs of its own
 constexpr int SLOT_TILE = 63 * FRAME_RUN;        // 3024 data bytes whose records one wave emits
 constexpr int SLOT_ROWS = SLAM_TILE_SLOTS;       // row slots per such tile: ceil(3024 / 11) = 275, rounded up to 4
