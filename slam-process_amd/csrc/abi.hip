@@ -965,7 +965,7 @@ extern "C" int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *
     int rc = SLAM_OK;
     if (stages & 4u) {
         const double sigma = bt->blur_sigma;
-        kern_by_value kv;
+        kern_by_value kv = {};
         if (sigma != sigma) rc = slam_fail(ctx, SLAM_E_INVALID, "blur sigma is NaN");
         else if (sigma > 0) {
             // gaussian_kernel (excel_heatmap_v3.py:320-333) on the stack, same arithmetic as slam_gaussian_kernel_host

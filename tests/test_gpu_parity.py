@@ -1161,13 +1161,16 @@ def test_batched_pipeline_upscaled_table(mapping, lut, opts):
     assert torch.equal(again, pipe.tiles[:F])
 
 
-def test_wide_axis_without_the_full_grid_equals_the_64_entry_table(mapping, lut):
+@pytest.mark.parametrize("sparse", [False, True])
+def test_wide_axis_without_the_full_grid_equals_the_64_entry_table(mapping, lut, sparse):
     """With the up-scaled table but the reference's axis rule (rows and columns are the angles that occur), only the
     table's own 64 angles can occur: matrix, blur and tile must be those of the 64-entry table, bit for bit."""
     import torch
     from slamhip import synth
     from slamhip.pipeline import FramePipeline, synth_frames
     B, N, F = 16, 1024, 3
+    if sparse:                                         # beams that share angles, beams without one: 28 distinct angles
+        mapping = {i: float(i // 2) for i in range(0, 64) if i % 7}
     tl = synth.text_len(B, N)
     stride = ((tl + 255) // 256) * 256
     text = synth_frames(F, B, N, first_frame=9)
