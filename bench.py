@@ -194,11 +194,10 @@ def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_o
     fpl = frames_per_launch_of(merged[dom]["launches"])
     ach = alg[dom] * fpl / (per * 1e-3) / 1e9
     traffic, note = None, None
+    import glob
     tag = f"{B}x{N}" + (f"_up{upscale}" if upscale > 1 else "")
-    cands = [os.path.join(ROOT, "profiles", f"r2_pmc_traffic_{tag}.json"), os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")]
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True)   # newest first; shape checked below
     for pmc in cands:
-        if not os.path.exists(pmc):
-            continue
         pj = json.load(open(pmc))                 # HBM bytes per launch from committed rocprofv3 PMC passes of this shape
         parts = [k for k in KERNEL_GROUPS.get(dom, (dom,)) if k in pj["kernels"]]
         if pj.get("shape") == [B, N] and pj.get("upscale", 1) == upscale and parts:

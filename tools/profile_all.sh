@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 profiles, run from the repo root on the GPU box; results under gpurun_out/prof2 (copy what is kept into
-# profiles/).  One rocprofv3 run per pass, each under its own time limit; any failure ends the script.
+# Every profile of the bench, run from the repo root on the GPU box; results under gpurun_out/prof2 (copy what is kept
+# into profiles/).  One rocprofv3 run per pass, each under its own time limit; any failure ends the script.
 #   1. kernel trace + stats of the default bench command (the line it printed is kept beside the trace)
 #   2. FETCH_SIZE and WRITE_SIZE passes of the headline shape -> per-kernel HBM traffic
 #   3. one pass of eight SQ counters for each of the three shapes
