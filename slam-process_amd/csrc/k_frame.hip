@@ -642,10 +642,15 @@ __device__ __forceinline__ void fill_slot_tile(uint32_t *tile, const src_view &s
         tile[d] = d < FRAME_RUN / 4 ? 0u : load_data_dword<MODE, true>(sv, 4u * (d - FRAME_RUN / 4), bad);
 }
 
-template <int MODE>
 #ifndef SLAM_ONEPASS_WAVES
 #define SLAM_ONEPASS_WAVES 4
 #endif
+// Measurement builds only (tools/exp_framing_bound.py): bit 0 leaves the row columns unwritten, bit 1 the row bits,
+// to time what the kernel costs without its stores.  The results of such a build are wrong; the default is 0.
+#ifndef SLAM_EXP_SKIP
+#define SLAM_EXP_SKIP 0
+#endif
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLAM_ONEPASS_WAVES)))      // 4 waves per SIMD (<= 128 VGPRs); 5 spills: 10.0 instead of 7.6 ms
 void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
 {
@@ -727,7 +732,7 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
         }
         wave_lds_sync();
         // whole slot block of the tile, full-width stores (slots past the tile's count hold leftovers)
-        {
+        if (!(SLAM_EXP_SKIP & 1) || t == 0xFFFFFFFFu) {
             constexpr uint32_t Q = SLOT_ROWS / 4;                    // 69 16-byte pieces per dword column
             const size_t rb = (size_t)f * out.row_cap + (size_t)t * SLOT_ROWS;
             const uint4 *s4 = reinterpret_cast<const uint4 *>(stg);
@@ -794,7 +799,7 @@ void k_frame_onepass(frame_src src, rows_out out, uint32_t *stats)
                 const uint32_t live = __builtin_amdgcn_udot4(liv7, 0x08040201u, 0u, false) >> 7;
                 // FLAG == 1 bits ride in the top nibble, so the correction need not read the flag column again
                 const uint32_t flag1 = g < NG ? (__builtin_amdgcn_udot4(s1[g] & 0x01010101u, 0x08040201u, 0u, false) & live) : 0u;
-                if (g < NG) rm[g] = (uint16_t)(bound | (base << 4) | (live << 8) | (flag1 << 12));
+                if (g < NG && (!(SLAM_EXP_SKIP & 2) || t == 0xFFFFFFFFu)) rm[g] = (uint16_t)(bound | (base << 4) | (live << 8) | (flag1 << 12));
                 const uint32_t c = __popc(base);                                   // 0, 1 or 2 baselines in four rows
                 const uint64_t m1 = __ballot(c >= 1u), m2 = __ballot(c >= 2u);
                 if (c) {
