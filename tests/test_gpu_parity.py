@@ -15,6 +15,7 @@ from oracle import slam_oracle as O
 pytestmark = pytest.mark.gpu
 
 REL = 1e-12
+FUZZ_SCALE = int(os.environ.get("SLAMHIP_FUZZ_SCALE", "1"))      # widens the fixed-count fuzz loops for a long run
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +75,7 @@ def test_truncated_captures_bit_exact(ops, i):
 def test_tokenizer_fuzz_against_oracle(ops):
     rng = np.random.default_rng(7)
     alphabet = np.frombuffer(b"0123456789abcdefABCDEFxX \t\n\r\x0b\x0c\x1c\x1f\x00gG,-\xc2\x85\xa0\xe2\x80\x82\xa8\xe3\xe1\x9a\xef\xbb\xbf\xf0\x9f\xff\xc0\xed\xf4\x90", np.uint8)
-    for trial in range(40):
+    for trial in range(40 * FUZZ_SCALE):
         n = int(rng.integers(1, 6000))
         t = alphabet[rng.integers(0, len(alphabet), n)].tobytes()
         exp = O.read_bytes(t)
@@ -91,7 +92,7 @@ def test_framing_fuzz_against_oracle(ops):
     rng = np.random.default_rng(11)
     pool = np.array([0x33, 0xCC, 0x05, 0xC7, 0x41, 0x7F, 0x81, 0xBF, 0x00, 0xFF, 0x33, 0xCC], np.uint8)
     rec = np.array([0x33, 0x05, 0xC7, 0x41, 0x42, 0x43, 0x44, 0x45, 0x81, 0x82, 0x83], np.uint8)
-    for trial in range(30):
+    for trial in range(30 * FUZZ_SCALE):
         parts = []
         for _ in range(int(rng.integers(1, 400))):
             if rng.random() < 0.6:
@@ -140,7 +141,7 @@ def test_unit_tables(ops):
 
 def test_correct_fuzz_against_oracle(ops):
     rng = np.random.default_rng(3)
-    for trial in range(12):
+    for trial in range(12 * FUZZ_SCALE):
         n = int(rng.integers(1, 30000))
         ue = np.sort(rng.integers(0, 64, n)) if trial % 3 == 0 else (np.arange(n) // max(1, int(rng.integers(1, 200)))) % 64
         flag = (rng.random(n) < 0.08).astype(np.int64)
@@ -968,6 +969,83 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
                 for k in kept_o:
                     assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (seed, f, k)
         del pipe, text
+        print(f"grammar fuzz seed {seed} (text={as_text}): {len(streams)} streams equal", flush=True)
+
+
+def test_batched_whole_chain_fuzz(lut):
+    """The batched call end to end on grammar streams with random settings per batch: beam tables with holes and
+    shared angles, the up-scaled table at every factor, blur from none to wide, linear and log scales with and without
+    limits, tiles of odd sizes.  Per frame the mean matrix, the blurred matrix, the colour limits and the tile against
+    the oracle run on the device's kept rows (those are held to the oracle by the fuzz above)."""
+    import torch
+    from slamhip.pipeline import FramePipeline
+    rng = np.random.default_rng(4242)
+    seen = {"ok": 0, "empty": 0, "limits": 0}
+    for trial in range(10 * FUZZ_SCALE):
+        streams = [_grammar_stream(rng) for _ in range(10)]
+        beams = rng.choice(64, int(rng.choice([64, 64, 40, 9, 2])), replace=False)
+        share = int(rng.integers(1, 4))
+        mp = {int(b): float(np.round((int(b) // share) * 1.5 - 30.0, 3)) for b in beams}
+        up = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        sigma = float(rng.choice([0.0, 0.4, 1.0, 2.3]))
+        use_log = bool(rng.random() < 0.4)
+        given = rng.random() < 0.3
+        vmin = float(rng.uniform(10000, 60000)) if given else None
+        vmax = float(rng.uniform(30000, 100000)) if given else None
+        W, H = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        offs, lens, blob = [], [], bytearray()
+        for p in streams:
+            while len(blob) % 16:
+                blob.append(0)
+            offs.append(len(blob)); lens.append(len(p)); blob += p
+        blob += bytes(64)
+        text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+        pipe = FramePipeline(len(streams), max(max(lens), 1), tile_w=W, tile_h=H, mapping=mp, lut=lut, src_is_bytes=True,
+                             upscale=up, blur_sigma=sigma, use_log=use_log, vmin=vmin, vmax=vmax)
+        pipe.set_layout(offs, lens)
+        pipe.run(text)
+        st = pipe.stats_host()
+        what = (trial, up, sigma, use_log, vmin, vmax, W, H, len(mp))
+        for f in range(len(streams)):
+            kept = pipe.frame_kept(f, st)
+            mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mp, upscale=up)
+            tile = pipe.frame_tile(f)
+            if mat.size == 0 or not np.isfinite(mat).any():          # no kept row with both beams in the table
+                assert int(st[f, 9]) == 1 and not tile[..., 3].any(), (what, f)
+                seen["empty"] += 1
+                continue
+            ob = O.blur_nan_aware(mat, sigma)
+            try:
+                r = O.render(ob, aod, aoa, lut, use_log=use_log, vmin=vmin, vmax=vmax, blur_sigma=0.0, W=W, H=H)
+            except ValueError as ex:
+                assert "vmin" in str(ex), (what, f, str(ex))
+                assert int(st[f, 9]) == 2 and not tile[..., 3].any(), (what, f)
+                seen["limits"] += 1
+                continue
+            assert int(st[f, 9]) == 0, (what, f)
+            full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
+            assert np.array_equal(aod_g, aod) and np.array_equal(aoa_g, aoa), (what, f)
+            assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True), (what, f)
+            fin = np.isfinite(ob)
+            assert np.array_equal(np.isfinite(bl), fin), (what, f)
+            assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL, (what, f)
+            # colours from the device's own blurred values: a last-place difference in the blur may move a bin edge
+            r = O.render(bl, aod, aoa, lut, use_log=use_log, vmin=vmin, vmax=vmax, blur_sigma=0.0, W=W, H=H)
+            assert (lo, hi) == (r["vmin"], r["vmax"]), (what, f)
+            if use_log:
+                # log10 may differ in the last place between libraries: one LUT step in a cell at a bin edge
+                d = np.abs(tile.astype(int) - r["tile"].astype(int)).max(axis=2)
+                colmap, rowmap = O.raster_index_maps(O.edges(aoa), O.edges(aod), W, H)
+                cell_of = rowmap[:, None].astype(np.int64) * 4096 + colmap[None, :]
+                off, shown = len(np.unique(cell_of[d > 0])), len(np.unique(cell_of))
+                assert d.max() <= 12 and off <= max(1, shown // 50), (what, f, off, shown)
+            else:
+                assert np.array_equal(tile, r["tile"]), (what, f)
+            seen["ok"] += 1
+        del pipe, text
+        if trial % 10 == 9:
+            print(f"whole-chain fuzz: {trial + 1} batches, {seen}", flush=True)
+    assert seen["ok"] >= 3 * FUZZ_SCALE, seen
 
 
 def test_render_stages_fuzz(ops, lut):
@@ -1026,6 +1104,8 @@ def test_render_stages_fuzz(ops, lut):
         else:
             assert d.max() == 0 and np.array_equal(tile, r["tile"]), case
         outcomes["ok"] += 1
+        if case % 100 == 99:
+            print(f"render fuzz: {case + 1} cases, {outcomes}", flush=True)
     assert outcomes["ok"] >= n_cases // 2, outcomes
 
 
