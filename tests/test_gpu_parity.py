@@ -950,8 +950,15 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
             offs.append(len(blob)); lens.append(len(p)); blob += p
         blob += b"\x20" * 64
         text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+        # the reference's constants in the first batch, then a draw per batch: cycles on and off the streams' clock
+        # grid, tolerances from none to everything, moduli that are and are not powers of two
+        cyc, tol, mod = 61000, 500, 64
+        if seed > 0:
+            cyc = int(rng.choice([61000, 61000, 60999, 30500, 1000, 7, (1 << 24) + 43]))
+            tol = int(rng.choice([500, 0, 3, cyc // 2, cyc, 700]))
+            mod = int(rng.choice([64, 64, 10, 255, 1, 128]))
         pipe = FramePipeline(len(streams), max(max(lens), 1), tile_w=32, tile_h=32, mapping=mapping, lut=lut,
-                             src_is_bytes=not as_text)
+                             src_is_bytes=not as_text, cycle=cyc, tol=tol, mod_base=mod)
         pipe.set_layout(offs, lens)
         pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
         st = pipe.stats_host()
@@ -963,13 +970,14 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
             for k in rows_o:
                 assert np.array_equal(rows[k], rows_o[k]), (seed, f, k)
             if v:
-                kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"])
-                assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), (seed, f)
+                kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"],
+                                                    cyc, tol, mod)
+                assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), (seed, f, cyc, tol, mod)
                 kept = pipe.frame_kept(f, st)
                 for k in kept_o:
-                    assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (seed, f, k)
+                    assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (seed, f, k, cyc, tol, mod)
         del pipe, text
-        print(f"grammar fuzz seed {seed} (text={as_text}): {len(streams)} streams equal", flush=True)
+        print(f"grammar fuzz seed {seed} (text={as_text}, cycle {cyc}, tol {tol}, mod {mod}): {len(streams)} streams equal", flush=True)
 
 
 def test_batched_whole_chain_fuzz(lut):
