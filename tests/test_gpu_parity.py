@@ -980,6 +980,88 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
         print(f"grammar fuzz seed {seed} (text={as_text}, cycle {cyc}, tol {tol}, mod {mod}): {len(streams)} streams equal", flush=True)
 
 
+def _sweep_frame(rng, n, mean_len, p_flag, jitter) -> bytes:
+    """n records in sweeps of random length (UE ramps 0 -> 63, so a sweep is a group), FLAG = 1 with probability
+    p_flag, most of those repeating the RSS of the row before (baselines), clocks on the cycle grid +- jitter."""
+    lens = []
+    while sum(lens) < n:
+        lens.append(max(1, int(rng.exponential(mean_len))))
+    ue = np.concatenate([np.arange(l) * 64 // l for l in lens])[:n]
+    flag = rng.random(n) < p_flag
+    rss = rng.integers(15000, 93000, n)
+    src = np.maximum.accumulate(np.where(~flag, np.arange(n), 0))
+    rss = np.where(rng.random(n) < 0.85, rss[src], rss)                 # some handovers change the RSS: no baseline
+    clk = np.cumsum(61000 + rng.integers(-jitter, jitter + 1, n)) % (1 << 30)
+    if rng.random() < 0.3:
+        clk = (clk + int(rng.integers(0, 1 << 30))) % (1 << 30)          # the 30-bit clock wraps inside the frame
+    bs = rng.integers(0, 64, n)
+    rec = np.empty((n, 11), np.uint8)
+    rec[:, 0] = np.where(flag, 0xCC, 0x33)
+    rec[:, 1] = ue
+    rec[:, 2] = 0xC0 | bs
+    for j in range(5):
+        rec[:, 3 + j] = 0x40 | ((clk >> (6 * j)) & 63)
+    for j in range(3):
+        rec[:, 8 + j] = 0x80 | ((rss >> (6 * j)) & 63)
+    out = rec.reshape(-1)
+    if rng.random() < 0.5:                                               # a few damaged bytes: discards and resyncs
+        out = out.copy()
+        hit = rng.integers(0, len(out), int(rng.integers(1, 20)))
+        out[hit] = rng.integers(0, 256, len(hit))
+    return out.tobytes()
+
+
+def test_batched_correction_structure_fuzz(mapping, lut):
+    """Long frames with random sweep lengths and baseline densities in one batch: groups from a row to the whole frame,
+    phase tables from none to thousands of entries, so the three builds of the correction kernel, the deferred
+    workgroups and every sort path meet in mixed batches.  Counters, decoded rows and kept rows against the oracle."""
+    import torch
+    from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
+    rng = np.random.default_rng(77)
+    for trial in range(4 * FUZZ_SCALE):
+        frames, what = [], []
+        for _ in range(6):
+            n = int(rng.choice([300, 3000, 20000, 60000, 120000]))
+            mean_len = float(rng.choice([3, 60, 700, 4096, 20000, 10 ** 6]))
+            p_flag = float(rng.choice([0.0, 0.002, 0.02, 0.1, 0.4]))
+            jitter = int(rng.choice([0, 300, 600, 30000]))
+            while n * p_flag * min(n, mean_len) > 3e8:       # the oracle compares every row with every baseline of its group
+                n //= 2
+            frames.append(_sweep_frame(rng, n, mean_len, p_flag, jitter))
+            what.append((n, mean_len, p_flag, jitter))
+        cyc, tol, mod = 61000, 500, 64
+        if trial % 2:
+            cyc = int(rng.choice([61000, 60999, 1000, (1 << 24) + 43]))
+            tol = int(rng.choice([500, 0, cyc // 2, cyc]))
+            mod = int(rng.choice([64, 10, 255]))
+        offs, lens, blob = [], [], bytearray()
+        for p in frames:
+            while len(blob) % 16:
+                blob.append(0)
+            offs.append(len(blob)); lens.append(len(p)); blob += p
+        blob += bytes(64)
+        text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
+        pipe = FramePipeline(len(frames), max(lens), tile_w=32, tile_h=32, mapping=mapping, lut=lut, src_is_bytes=True,
+                             cycle=cyc, tol=tol, mod_base=mod)
+        pipe.set_layout(offs, lens)
+        pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+        st = pipe.stats_host()
+        for f, fb in enumerate(frames):
+            rows_o, v, d = O.parse_groups(np.frombuffer(fb, np.uint8))
+            assert (int(st[f, 2]), int(st[f, 3])) == (v, d), (trial, f, what[f])
+            rows = pipe.frame_rows(f, st)
+            for k in rows_o:
+                assert np.array_equal(rows[k], rows_o[k]), (trial, f, k, what[f])
+            kept_o, ng, nb = O.filter_corrected(rows_o["flag"], rows_o["ue"], rows_o["bs"], rows_o["rss"], rows_o["clk"],
+                                                cyc, tol, mod)
+            assert (int(st[f, 4]), int(st[f, 5]), int(st[f, 6])) == (ng, nb, len(kept_o["ue"])), (trial, f, what[f], cyc, tol, mod)
+            kept = pipe.frame_kept(f, st)
+            for k in kept_o:
+                assert np.array_equal(kept[k].astype(np.int64), kept_o[k]), (trial, f, k, what[f], cyc, tol, mod)
+        del pipe, text
+        print(f"structure fuzz batch {trial} (cycle {cyc}, tol {tol}, mod {mod}): equal", flush=True)
+
+
 def test_batched_whole_chain_fuzz(lut):
     """The batched call end to end on grammar streams with random settings per batch: beam tables with holes and
     shared angles, the up-scaled table at every factor, blur from none to wide, linear and log scales with and without
