@@ -159,7 +159,7 @@ int slam_render(slam_ctx *ctx, const double *mat, int h, int w,
 typedef struct slam_batch {
     /* inputs */
     const uint8_t *text_dev;      /* all frames' text; readable up to 32 bytes past the last frame */
-    const uint64_t *text_off_dev; /* [F] byte offset of each frame's text                        */
+    const uint64_t *text_off_dev; /* [F] byte offset of each frame's text (any alignment)        */
     const uint32_t *text_len_dev; /* [F] text bytes of each frame                                */
     uint32_t n_frames;            /* F, at most 65535 per call                                    */
     uint32_t max_text_len;        /* max over frames of text_len (host-known upper bound; a frame */

@@ -943,10 +943,14 @@ def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text
         if as_text:
             payloads = [("« " if rng.random() < 0.7 else "").encode("utf-8") + "".join(f"{b:02X} " for b in s).encode("ascii")
                         for s in streams]
+        # frames start at any byte (the first batch keeps 16-byte starts), with bytes of other frames right before and after
         offs, lens, blob = [], [], bytearray()
         for p in payloads:
-            while len(blob) % 16:
-                blob.append(0x20)
+            if seed == 0:
+                while len(blob) % 16:
+                    blob.append(0x20)
+            else:
+                blob += b"3C "[: int(rng.integers(0, 4))] * int(rng.integers(0, 7))
             offs.append(len(blob)); lens.append(len(p)); blob += p
         blob += b"\x20" * 64
         text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
