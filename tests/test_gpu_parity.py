@@ -1081,6 +1081,10 @@ def test_batched_whole_chain_fuzz(lut):
         share = int(rng.integers(1, 4))
         mp = {int(b): float(np.round((int(b) // share) * 1.5 - 30.0, 3)) for b in beams}
         up = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        # an up-scaled table usually with the full grid; without it the angles that occur are the table's own, and the
+        # results must be those of the 64-entry table
+        fg = None if up == 1 else bool(rng.random() < 0.7)
+        o_up = 1 if fg is False else up
         sigma = float(rng.choice([0.0, 0.4, 1.0, 2.3]))
         use_log = bool(rng.random() < 0.4)
         given = rng.random() < 0.3
@@ -1095,14 +1099,14 @@ def test_batched_whole_chain_fuzz(lut):
         blob += bytes(64)
         text = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).cuda()
         pipe = FramePipeline(len(streams), max(max(lens), 1), tile_w=W, tile_h=H, mapping=mp, lut=lut, src_is_bytes=True,
-                             upscale=up, blur_sigma=sigma, use_log=use_log, vmin=vmin, vmax=vmax)
+                             upscale=up, full_grid=fg, blur_sigma=sigma, use_log=use_log, vmin=vmin, vmax=vmax)
         pipe.set_layout(offs, lens)
         pipe.run(text)
         st = pipe.stats_host()
-        what = (trial, up, sigma, use_log, vmin, vmax, W, H, len(mp))
+        what = (trial, up, fg, sigma, use_log, vmin, vmax, W, H, len(mp))
         for f in range(len(streams)):
             kept = pipe.frame_kept(f, st)
-            mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mp, upscale=up)
+            mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mp, upscale=o_up)
             tile = pipe.frame_tile(f)
             if mat.size == 0 or not np.isfinite(mat).any():          # no kept row with both beams in the table
                 assert int(st[f, 9]) == 1 and not tile[..., 3].any(), (what, f)
@@ -1119,7 +1123,11 @@ def test_batched_whole_chain_fuzz(lut):
             assert int(st[f, 9]) == 0, (what, f)
             full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
             assert np.array_equal(aod_g, aod) and np.array_equal(aoa_g, aoa), (what, f)
-            assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True), (what, f)
+            mean_o = np.where(co > 0, so / np.maximum(co, 1), np.nan)
+            if fg is False:           # the wide grid holds the 64-entry table's cells at every up-th entry, nothing between
+                assert np.isfinite(full).sum() == np.isfinite(mean_o).sum(), (what, f)
+                full = full[::up, ::up]
+            assert np.array_equal(full, mean_o, equal_nan=True), (what, f)
             fin = np.isfinite(ob)
             assert np.array_equal(np.isfinite(bl), fin), (what, f)
             assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= REL, (what, f)
