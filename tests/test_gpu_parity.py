@@ -1072,9 +1072,10 @@ def test_batched_whole_chain_fuzz(lut):
     limits, tiles of odd sizes.  Per frame the mean matrix, the blurred matrix, the colour limits and the tile against
     the oracle run on the device's kept rows (those are held to the oracle by the fuzz above)."""
     import torch
+    from slamhip._lib import SlamError, E_CAPACITY
     from slamhip.pipeline import FramePipeline
     rng = np.random.default_rng(4242)
-    seen = {"ok": 0, "empty": 0, "limits": 0}
+    seen, n_noalloc = {"ok": 0, "empty": 0, "limits": 0}, 0
     for trial in range(10 * FUZZ_SCALE):
         streams = [_grammar_stream(rng) for _ in range(10)]
         beams = rng.choice(64, int(rng.choice([64, 64, 40, 9, 2])), replace=False)
@@ -1101,9 +1102,19 @@ def test_batched_whole_chain_fuzz(lut):
         pipe = FramePipeline(len(streams), max(max(lens), 1), tile_w=W, tile_h=H, mapping=mp, lut=lut, src_is_bytes=True,
                              upscale=up, full_grid=fg, blur_sigma=sigma, use_log=use_log, vmin=vmin, vmax=vmax)
         pipe.set_layout(offs, lens)
-        pipe.run(text)
+        # every other batch on the library's fixed scratch, which still holds what earlier batches of other shapes left
+        noalloc = trial % 2 == 1
+        if noalloc:
+            try:
+                pipe.run(text, noalloc=True)
+            except SlamError as ex:
+                assert ex.code == E_CAPACITY, str(ex)          # a shape beyond the fixed scratch: the ordinary call
+                noalloc = False
+        if not noalloc:
+            pipe.run(text)
+        n_noalloc += int(noalloc)
         st = pipe.stats_host()
-        what = (trial, up, fg, sigma, use_log, vmin, vmax, W, H, len(mp))
+        what = (trial, up, fg, sigma, use_log, vmin, vmax, W, H, len(mp), noalloc)
         for f in range(len(streams)):
             kept = pipe.frame_kept(f, st)
             mat, aod, aoa, so, co = O.pivot_mean(kept["ue"], kept["bs"], kept["rss"].astype(np.int64), mp, upscale=o_up)
@@ -1146,7 +1157,7 @@ def test_batched_whole_chain_fuzz(lut):
             seen["ok"] += 1
         del pipe, text
         if trial % 10 == 9:
-            print(f"whole-chain fuzz: {trial + 1} batches, {seen}", flush=True)
+            print(f"whole-chain fuzz: {trial + 1} batches, {seen}, on the fixed scratch: {n_noalloc}", flush=True)
     assert seen["ok"] >= 3 * FUZZ_SCALE, seen
 
 
