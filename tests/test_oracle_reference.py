@@ -111,6 +111,58 @@ def test_reference_functions_on_a_synthetic_frame(ref, tmp_path, shape):
     assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), res)
 
 
+def test_parse_and_correction_fuzz_against_the_reference(ref, tmp_path):
+    """Random streams from the record grammar the GPU fuzz uses (sweeps, handovers, damaged records, stray flag bytes,
+    noise, record-free stretches, cuts) through the reference's own _read_bytes, _parse_groups and the group loop of
+    process_excel_filtered, against the oracle: the generator the HIP path is fuzzed with is covered by the same pin."""
+    import importlib.util
+    import pandas as pd
+    from pathlib import Path
+    from test_gpu_parity import _grammar_stream
+    spec = importlib.util.spec_from_file_location("ref_bs_beam_correction_fuzz", os.path.join(REFERENCE, "bs_beam_correction.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    lg = logging.getLogger("pin")
+    rng = np.random.default_rng(31337)
+    n_rows = n_kept = 0
+    for trial in range(int(os.environ.get("SLAMHIP_FUZZ_REF_STREAMS", "40"))):
+        stream = _grammar_stream(rng)
+        sep = [" ", " ", "\n", "  ", "\t"]
+        text = ("« " if rng.random() < 0.5 else "") + "".join(
+            (f"{b:02X}" if rng.random() < 0.98 else f"{b:02x}") + sep[int(rng.integers(0, len(sep)))] for b in stream)
+        if rng.random() < 0.3:
+            text += "zz 1 123 0x41 G7 "                                  # tokens the reader skips
+        p = tmp_path / f"s{trial}.txt"
+        p.write_bytes(text.encode("utf-8"))
+        by_ref = ref._read_bytes(Path(p), lg)
+        by = O.read_bytes(text.encode("utf-8"))
+        assert by.tolist() == by_ref, trial
+        rows_ref, v_ref, d_ref = ref._parse_groups(by_ref, lg)
+        rows, v, d = O.parse_groups(by)
+        assert (v, d) == (v_ref, d_ref), trial
+        if not v:
+            continue
+        arr = np.array(rows_ref, dtype=np.int64)
+        for j, k in enumerate(("flag", "ue", "bs", "rss", "clk")):
+            assert np.array_equal(rows[k].astype(np.int64), arr[:, j]), (trial, k)
+        df = B._coerce_types(pd.DataFrame(rows_ref, columns=[B.FLAG_COL, B.UE_BEAM_COL, B.BS_BEAM_COL, B.RSS_COL, B.CLK_COL]))
+        df["_gid"] = B._detect_groups(df)
+        pieces, nb_ref = [], 0
+        for g, sub in df.groupby("_gid", sort=True):
+            bl = B._identify_baselines(sub)
+            nb_ref += len(bl)
+            f = B._filter_group_corrected(sub, bl)
+            if not f.empty:
+                pieces.append(f)
+        kept, ng, nb = O.filter_corrected(*arr.T)
+        assert (ng, nb) == (int(df["_gid"].max()) + 1, nb_ref), trial
+        res = pd.concat(pieces, ignore_index=True).to_numpy().astype(np.int64) if pieces else np.zeros((0, 4), np.int64)
+        assert np.array_equal(np.stack([kept[k] for k in ("ue", "bs", "rss", "clk")], 1), res), trial
+        n_rows += v
+        n_kept += len(res)
+    assert n_rows > 5000 and n_kept > 500, (n_rows, n_kept)
+
+
 def test_blur_against_the_reference_for_wide_and_narrow_kernels():
     """gaussian_blur_nan_aware of the reference on small, non-square matrices with holes, kernels from 3 x 3 to wider
     than the matrix (edge padding repeats the border) against the oracle's restatement."""
