@@ -932,10 +932,10 @@ def _grammar_stream(rng) -> bytes:
 @pytest.mark.parametrize("as_text", [False, True])
 def test_grammar_fuzz_of_the_batched_decode_and_correction(mapping, lut, as_text):
     """Random streams from a record grammar, as raw bytes and as capture text, in one batch per seed: counters, decoded
-    rows and kept rows against the oracle.  SLAMHIP_FUZZ_SEEDS widens the run (default 2 seeds of 150 streams)."""
+    rows and kept rows against the oracle.  SLAMHIP_FUZZ_SEEDS widens the run (default 4 seeds of 150 streams)."""
     import torch
     from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
-    n_seeds = int(os.environ.get("SLAMHIP_FUZZ_SEEDS", "2"))
+    n_seeds = int(os.environ.get("SLAMHIP_FUZZ_SEEDS", "4"))
     for seed in range(n_seeds):
         rng = np.random.default_rng(9000 + seed + (500 if as_text else 0))
         streams = [_grammar_stream(rng) for _ in range(150)]
@@ -1022,7 +1022,7 @@ def test_batched_correction_structure_fuzz(mapping, lut):
     import torch
     from slamhip.pipeline import FramePipeline, STAGE_DECODE, STAGE_CORRECT
     rng = np.random.default_rng(77)
-    for trial in range(4 * FUZZ_SCALE):
+    for trial in range(8 * FUZZ_SCALE):
         frames, what = [], []
         for _ in range(6):
             n = int(rng.choice([300, 3000, 20000, 60000, 120000]))
@@ -1076,7 +1076,7 @@ def test_batched_whole_chain_fuzz(lut):
     from slamhip.pipeline import FramePipeline
     rng = np.random.default_rng(4242)
     seen, n_noalloc = {"ok": 0, "empty": 0, "limits": 0}, 0
-    for trial in range(10 * FUZZ_SCALE):
+    for trial in range(30 * FUZZ_SCALE):
         streams = [_grammar_stream(rng) for _ in range(10)]
         beams = rng.choice(64, int(rng.choice([64, 64, 40, 9, 2])), replace=False)
         share = int(rng.integers(1, 4))
@@ -1167,7 +1167,7 @@ def test_render_stages_fuzz(ops, lut):
     from none to wider than the grid, linear and log scales with and without limits, tiles of odd sizes."""
     from slamhip._lib import SlamError, E_ALLNAN, E_LIMITS
     rng = np.random.default_rng(606)
-    n_cases = int(os.environ.get("SLAMHIP_FUZZ_CASES", "60"))
+    n_cases = int(os.environ.get("SLAMHIP_FUZZ_CASES", "200"))
     outcomes = {"ok": 0, "empty": 0, "limits": 0}
     for case in range(n_cases):
         beams = rng.choice(64, int(rng.integers(1, 65)), replace=False)
