@@ -586,6 +586,21 @@ def test_plain_c_tour_of_every_host_entry_point():
     assert r.returncode == 0 and r.stdout.startswith("tour ok"), (r.stdout, r.stderr)
 
 
+def test_plain_c_host_of_the_batched_entry_points():
+    """examples/cabi_batch.c: slam_process_frames_dev, slam_process_frames_noalloc_dev and slam_raster_dev from C with
+    device memory from the HIP runtime: counters consistent with the slots' counts, frame 0 equal to what the
+    host-pointer entry points give, the allocation-free call and the repainted tiles byte for byte the same."""
+    import subprocess
+    import __graft_entry__ as G
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "cabi_batch")
+    if not os.path.exists(exe):
+        G.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "batch ok" in r.stdout, (r.stdout, r.stderr)
+    assert "frame_onepass" in r.stdout and "rows_finish" in r.stdout            # its own timer table names the kernels
+
+
 def test_complete_capture_end_to_end():
     """A complete capture of the reference (622 KB of text, 835 discarded groups, 8 sweeps) through the batched path:
     counters and kept rows as the reference's functions gave them, the mean matrix and the blurred matrix of its

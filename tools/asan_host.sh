@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host-side AddressSanitizer build of the library and of the plain-C host (device code is built as usual), into
 # build/asan/.  Build here, then on the GPU box:
-#   ASAN_OPTIONS=verify_asan_link_order=0:detect_leaks=0:protect_shadow_gap=0 build/asan/cabi_demo_asan capture.txt      (and build/asan/cabi_tour_asan, no arguments)
+#   ASAN_OPTIONS=verify_asan_link_order=0:detect_leaks=0:protect_shadow_gap=0 build/asan/cabi_demo_asan capture.txt      (and build/asan/cabi_tour_asan, build/asan/cabi_batch_asan, no arguments)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 rt=$(dirname "$(find /opt/rocm/lib/llvm/lib/clang -name 'libclang_rt.asan-x86_64.so' | head -1)")
@@ -16,4 +16,7 @@ wait
     -o cabi_demo_asan -L. -lslamhip_asan -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$rt"
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=address -shared-libasan -I"$root/include" "$root/examples/cabi_tour.c" \
     -o cabi_tour_asan -L. -lslamhip_asan -lm -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$rt"
-echo "built $root/build/asan/cabi_demo_asan and cabi_tour_asan"
+/opt/rocm/lib/llvm/bin/clang -O1 -g -fsanitize=address -shared-libasan -D__HIP_PLATFORM_AMD__ -I"$root/include" -I/opt/rocm/include \
+    "$root/examples/cabi_batch.c" -o cabi_batch_asan -L. -lslamhip_asan -L/opt/rocm/lib -lamdhip64 -lm \
+    -Wl,-rpath,'$ORIGIN' -Wl,-rpath,"$rt" -Wl,-rpath,/opt/rocm/lib
+echo "built $root/build/asan/cabi_demo_asan, cabi_tour_asan and cabi_batch_asan"
