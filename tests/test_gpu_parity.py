@@ -1628,3 +1628,59 @@ def test_batched_call_with_counts_left_to_the_workspace(mapping, lut):
     assert np.array_equal(pipe.stats_host(), st_ref) and int(st_ref[:, 6].min()) > 1000
     assert torch.equal(pipe.tiles[:F], ref.tiles[:F]) and torch.equal(pipe.matrix.view(torch.int64), ref.matrix.view(torch.int64))
     assert torch.equal(pipe.blurred.view(torch.int64), ref.blurred.view(torch.int64))
+
+
+def test_two_threads_with_a_ctx_each(mapping, lut):
+    """A ctx per thread is the library's threading rule: two host threads, each with its own pipeline (its own ctx and
+    workspace) on its own stream, run different batches at the same time; every round gives the bytes a lone run gives."""
+    import threading
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, synth_frames
+    B, N, F = 16, 1024, 4
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    texts = [synth_frames(F, B, N, first_frame=40 + 10 * i) for i in range(2)]
+
+    def outputs(pipe):
+        torch.cuda.synchronize()
+        st = pipe.stats_host().copy()
+        return (st, pipe.tiles[:F].clone(), [pipe.frame_kept(f, st) for f in range(F)], pipe.matrix.clone())
+
+    alone = []
+    for i in range(2):
+        pipe = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+        pipe.set_uniform_layout(F, stride, tl)
+        pipe.run(texts[i])
+        alone.append(outputs(pipe))
+        del pipe
+    assert not np.array_equal(alone[0][0], alone[1][0])              # the two batches do differ
+
+    errors, start = [], threading.Barrier(2)
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream()
+            pipe = FramePipeline(F, tl, tile_w=128, tile_h=96, mapping=mapping, lut=lut)
+            pipe.set_uniform_layout(F, stride, tl)
+            start.wait(timeout=60)
+            for rnd in range(8):
+                with torch.cuda.stream(stream):
+                    pipe.run(texts[i])
+                stream.synchronize()
+                st, tiles, kept, mat = outputs(pipe)
+                ok = (np.array_equal(st, alone[i][0]) and torch.equal(tiles, alone[i][1]) and
+                      torch.equal(mat.view(torch.int64), alone[i][3].view(torch.int64)))
+                for f in range(F):
+                    ok = ok and all(np.array_equal(kept[f][k], alone[i][2][f][k]) for k in kept[f])
+                if not ok:
+                    errors.append((i, rnd))
+        except Exception as ex:                                   # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
