@@ -193,7 +193,7 @@ def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_o
     per = merged[dom]["ms"] / merged[dom]["launches"]
     fpl = frames_per_launch_of(merged[dom]["launches"])
     ach = alg[dom] * fpl / (per * 1e-3) / 1e9
-    traffic, note = None, None
+    traffic, note, pipe_traffic = None, None, None
     import glob
     tag = f"{B}x{N}" + (f"_up{upscale}" if upscale > 1 else "")
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True)   # newest first; shape checked below
@@ -204,12 +204,14 @@ def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_o
             traffic = int(sum(pj["kernels"][k]["fetch_bytes_per_frame"] + pj["kernels"][k]["write_bytes_per_frame"]
                               for k in parts) * fpl)
             note = os.path.relpath(pmc, ROOT)
+            pipe_traffic = pj.get("pipeline_bytes_per_frame")      # every kernel of the batch, per frame
             break
     if traffic is None:
         note = f"no committed PMC pass for shape {tag}"
     roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=note,
-                alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5))
+                alg_bytes_per_launch=int(alg[dom] * fpl), frames_per_launch=fpl, avg_launch_ms=round(per, 5),
+                pipeline_traffic_per_frame=pipe_traffic)
     return table, roof, ach
 
 
@@ -412,7 +414,10 @@ def short_config(job, name, B, N, F, K, W, tile, upscale):
                pipeline_alg_GBps=round(res["fps_rank"] * res["alg_frame"] / 1e9, 1),
                pipeline_hbm_frac=round(res["fps_rank"] * res["alg_frame"] / 1e9 / HBM_PEAK_GBS, 4),
                dominant_kernel=dict(name=res["roofline"]["kernel"], avg_launch_ms=res["roofline"]["avg_launch_ms"],
-                                    alg_GBps=res["roofline"]["achieved"], frac=res["roofline"]["frac"]),
+                                    alg_GBps=res["roofline"]["achieved"], frac=res["roofline"]["frac"],
+                                    alg_bytes_per_launch=res["roofline"]["alg_bytes_per_launch"],
+                                    traffic=res["roofline"]["traffic"], traffic_source=res["roofline"]["traffic_source"]),
+               pipeline_traffic_per_frame=res["roofline"]["pipeline_traffic_per_frame"],
                top_kernels={k: dict(avg_ms=v["avg_ms"], share=v["share"], alg_GBps=v.get("alg_GBps")) for k, v in top})
     del pipe, text
     torch.cuda.empty_cache()

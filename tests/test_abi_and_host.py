@@ -291,7 +291,7 @@ def test_bench_kernel_accounting_groups_the_builds_and_never_exceeds_the_peak():
     traffic file of the shape that ran or says that there is none."""
     sys.path.insert(0, ROOT)
     import bench
-    nbytes, valid, kept, tile_bytes, F, K = 11.5e6, 1.05e6, 0.63e6, 4194304, 200, 5
+    nbytes, valid, kept, tile_bytes, F, K = 46.1e6, 4.19e6, 2.5e6, 4194304, 200, 5           # a 256 x 16384 frame
     kern = {"frame_onepass": (K, 40.0), "rows_finish": (K, 0.3), "rows_finish_mid": (K, 16.0), "rows_finish_rest": (K, 0.3),
             "pivot": (K, 3.5), "raster": (K, 0.0005), "bl_sort_small": (K, 1.5)}
     table, roof, ach = bench.kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / launches, 256, 16384, 1)
@@ -302,6 +302,11 @@ def test_bench_kernel_accounting_groups_the_builds_and_never_exceeds_the_peak():
     assert table["raster"]["alg_GBps"] is None and "alg_note" in table["raster"]          # would be far above the peak
     assert all(v.get("alg_GBps") is None or v["alg_GBps"] <= bench.HBM_PEAK_GBS for v in table.values())
     assert roof["kernel"] == "frame_onepass" and roof["peak"] == 8000.0 and roof["frac"] == round(roof["achieved"] / 8000.0, 4)
-    assert roof["traffic"] is None and "256x16384" in roof["traffic_source"]
+    # the traffic comes from the committed counter passes of the very shape, per launch like the algorithmic bytes
+    assert "256x16384" in roof["traffic_source"] and roof["traffic_source"].startswith("profiles/")
+    assert roof["alg_bytes_per_launch"] <= roof["traffic"] < 1.2 * roof["alg_bytes_per_launch"]
+    assert roof["pipeline_traffic_per_frame"] > 3.0 * nbytes + 11.0 * valid + 10.0 * kept
+    _t, roof_none, _a = bench.kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / launches, 128, 2048, 1)
+    assert roof_none["traffic"] is None and "128x2048" in roof_none["traffic_source"] and roof_none["pipeline_traffic_per_frame"] is None
     _t, roof2, _a = bench.kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: 800 * K / launches, 256, 4096, 1)
     assert roof2["traffic"] and roof2["traffic_source"].startswith("profiles/")
