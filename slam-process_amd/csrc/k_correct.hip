@@ -464,8 +464,13 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
 {
     __shared__ unsigned long long mid_keys[4][MID_SORT_MAX];
     __shared__ uint32_t mid_q[4][MID_SORT_MAX], mid_bs[4][MID_SORT_MAX];
+    __shared__ uint32_t wg_flags;                        // the frame's flag bits this workgroup found, one atomic at the end
     const uint32_t f = blockIdx.y, lane = lane_id();
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
+    const bool wide_cycle = (uint32_t)prm.cycle >= (1u << 24);          // phase and index do not fit one dword
+    uint32_t my_flags = 0;
+    if (threadIdx.x == 0) wg_flags = 0;
+    __syncthreads();
     const size_t gs = (size_t)f * (row_cap + 1);
     const size_t bsb = (size_t)f * ws.bl_cap;
     for (uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6); g < G; g += gridDim.x * 4) {
@@ -476,11 +481,9 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
         }
         // in the batched path rt_nbase is free: its entry f tells k_rows_finish that frame f has a group whose phase
         // table may not fit a wave's registers (bit 0) and k_bl_sort that one is left for it to sort (bit 2)
-        if (m > WAVE_SORT_MAX && bits.pay && lane == 0) {    // bit 3: a table the mid build of k_rows_finish cannot hold
-            // fire and forget: a load of the word first, to skip the atomic when the bits are there, makes the wave wait
-            // for it and cost 50 % more on frames of a thousand such groups
-            atomicOr(ws.rt_nbase + f, (m > MID_SORT_MAX ? 5u : 1u) | (m >= MID_TAB_CAP ? 8u : 0u));
-        }
+        // bit 3: a table the mid build of k_rows_finish cannot hold.  Gathered per workgroup: a frame of a thousand such
+        // groups would otherwise send a thousand atomics to one word
+        if (m > WAVE_SORT_MAX && bits.pay) my_flags |= (m > MID_SORT_MAX ? 5u : 1u) | (m >= MID_TAB_CAP ? 8u : 0u);
         if (m > MID_SORT_MAX) continue;
         if (m > WAVE_SORT_MAX) {
             unsigned long long *kk = mid_keys[threadIdx.x >> 6];
@@ -530,10 +533,10 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
                     sb[i] = bsv;
                     kv[e] = (r << 8) | i;
                 }
-                kk[i] = key;
+                if (wide_cycle) kk[i] = key;
             }
             wave_lds_fence();
-            if ((uint32_t)prm.cycle < (1u << 24)) {
+            if (!wide_cycle) {
                 // phase and index fit one dword: the whole network runs in registers and lane exchanges
                 if (P == 128) wave_sort_regs<2>(kv, lane); else wave_sort_regs<4>(kv, lane);
                 uint32_t run = 0;
@@ -666,6 +669,9 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
         }
         if (lane == 0) ws.grp_nd[gs + g] = (uint32_t)__popcll(km);
     }
+    if (my_flags && lane == 0) atomicOr(&wg_flags, my_flags);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_flags) atomicOr(ws.rt_nbase + f, wg_flags);
 }
 
 // Per group: sort baseline phases (clk_b mod cycle), keep the earliest baseline of each phase.
@@ -1099,7 +1105,6 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
         }
         if (!staged) return;
     }
-    uint32_t kept_wg = 0;                                // rows the workgroup kept, over all its blocks
     uint32_t in_lds_group = 0xFFFFFFFFu, P = 2;          // group whose table sits in t_rb / t_pay, its padded length
     uint32_t in_reg_group = 0xFFFFFFFFu, t_r = 0xFFFFFFFFu, t_x = 0, t_y = 0, t_z = 0;   // small table: entry `lane`
     uint32_t pv[7] = {0, 0, 0, 0, 0, 0, 0};              // its entries 7, 15, ..., 55 (wave-uniform)
@@ -1342,10 +1347,22 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
             *reinterpret_cast<V32 *>(out.clk + ob) = reinterpret_cast<const V32 *>(k_ck)[tid];
         }
         if (tid == 0) out.slot_cnt[(size_t)f * out.slot_stride + tile] = nk;
-        kept_wg += nk;
     }
-    // one atomic per workgroup: a long frame's kept counter is a hot word otherwise
-    if (tid == 0 && kept_wg) atomicAdd(stats + f * SLAM_STAT_WORDS + SLAM_STAT_KEPT, kept_wg);
+}
+
+// The frame's KEPT is the sum of its blocks' counts, added up by one wave per frame after the correction kernels: an
+// atomic per workgroup on the frame's counter made it a hot word on long frames (2,700 workgroups a frame at 1024 x 8192:
+// 3.18 -> 3.05 ms without them).  Set, not added: running the stage again gives the same counter.
+__global__ __launch_bounds__(256) void k_kept_total(uint32_t F, const uint32_t *kept_cnt, uint32_t kept_stride, uint32_t *stats)
+{
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (f >= F) return;
+    const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
+    const uint32_t nblk = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    uint32_t k = 0;
+    for (uint32_t b = lane; b < nblk; b += 64) k += kept_cnt[(size_t)f * kept_stride + b];
+    k = wave_sum(k);
+    if (lane == 0) stats[f * SLAM_STAT_WORDS + SLAM_STAT_KEPT] = k;
 }
 
 }  // namespace
@@ -1452,6 +1469,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         }
         SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, FIN_FULL, FIN_TPB_FULL>), dim3(wgs_full, F), block,
                     in, rt_max, ws.rt_nbound, w2, prm_k, out, stats, defer, ws.rt_nbase);
+        SLAM_LAUNCH(ctx, "kept_total", k_kept_total, dim3((F + 3) / 4), block, F, out.slot_cnt, out.slot_stride, stats);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_summarize", (k_rows_summarize<T8, T32>), grid, block, in, rt_max, og, ws.rt_nbound,
@@ -1465,11 +1483,12 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                 tile_bits());
     SLAM_LAUNCH(ctx, "bl_sort", k_bl_sort, dim3(F <= 8 ? 1024 : (F <= 64 ? 256 : 32), F), dim3(256), ws, in.row_cap, prm, stats,
                 tile_bits(), MID_SORT_MAX);
-    if (out.slot_cnt) {       // fused correction + kept rows into per-block slots; the kept total is accumulated
+    if (out.slot_cnt) {       // fused correction + kept rows into per-block slots
         if (og) return slam_fail(ctx, SLAM_E_INVALID, "slotted kept rows: whole-table mode only");
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
         SLAM_LAUNCH(ctx, "rows_finish_rest", (k_rows_finish<T8, T32, FIN_FULL, FIN_TPB_FULL>), dim3((rt_max + FIN_TPB_FULL - 1) / FIN_TPB_FULL, F), block,
                     in, rt_max, ws.rt_nbound, ws, prm_k, out, stats, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        SLAM_LAUNCH(ctx, "kept_total", k_kept_total, dim3((F + 3) / 4), block, F, out.slot_cnt, out.slot_stride, stats);
         return SLAM_OK;
     }
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, ws.rt_nbound, ws,

@@ -36,8 +36,8 @@ struct frame_src {
 struct frame_ws {               // device scratch of the framing stage
     uint32_t *summ;             // [F * nt_max * 11]
     uint8_t *tile_entry;        // [F * nt_max]
-    uint32_t *tile_off;         // [F * nt_max] records before each tile
-    uint32_t *tile_off_d;       // [F * nt_max] discards before each tile
+    uint32_t *tile_off;         // [F * nt_max] records before each tile (two-pass frames); single-pass frames: the
+    uint32_t *tile_off_d;       // [F * nt_max] discards before each tile ...  record / discard count of each workgroup
     uint8_t *dec;               // [F * dec_stride] decoded data bytes of text frames
     uint64_t dec_stride;
     static uint64_t dec_stride_for(uint32_t nt_max) { return (uint64_t)nt_max * FRAME_TILE + 256; }
