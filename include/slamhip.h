@@ -245,7 +245,8 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
  * (serial_hex_to_excel_v3.py:153-154), process_excel_filtered's data path
  * (bs_beam_correction.py:186-198) and process_excel_to_heatmap's data path
  * (excel_heatmap_v3.py:519-545) without the xlsx hops between them.
- * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones). */
+ * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones; a stage may be run
+ * again on the same buffers, its counters are set, not added to; the decode stage starts a frame's stats afresh). */
 int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
 
 /* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses

@@ -1684,3 +1684,31 @@ def test_two_threads_with_a_ctx_each(mapping, lut):
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors
+
+
+def test_stages_run_again_report_the_same_counters(mapping, lut):
+    """Counters are set, not accumulated: the correction stage run again on the decoded rows, the render stage run again
+    on the kept rows, and the whole call run again on the same buffers leave every stats word as the first run did."""
+    import torch
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, STAGE_CORRECT, STAGE_DECODE, STAGE_RENDER, synth_frames
+    B, N, F = 16, 1024, 3
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=70)
+    pipe = FramePipeline(F, tl, tile_w=64, tile_h=64, mapping=mapping, lut=lut)
+    pipe.set_uniform_layout(F, stride, tl)
+    pipe.run(text)
+    first, tiles = pipe.stats_host().copy(), pipe.tiles[:F].clone()
+    assert int(first[:, 6].min()) > 0
+    for stages in (STAGE_CORRECT, STAGE_CORRECT | STAGE_RENDER, STAGE_RENDER, STAGE_DECODE | STAGE_CORRECT | STAGE_RENDER):
+        pipe.run(text, stages=stages)
+        assert np.array_equal(pipe.stats_host(), first), stages
+    assert torch.equal(pipe.tiles[:F], tiles)
+    # the decode stage starts a frame's stats afresh: its own words come back, the later stages' words are cleared
+    pipe.run(text, stages=STAGE_DECODE)
+    st = pipe.stats_host()
+    own = [0, 1, 2, 3, 14, 15]
+    assert np.array_equal(st[:, own], first[:, own]) and not st[:, 4:14].any()
+    pipe.run(text, stages=STAGE_CORRECT | STAGE_RENDER)
+    assert np.array_equal(pipe.stats_host(), first) and torch.equal(pipe.tiles[:F], tiles)
