@@ -246,9 +246,11 @@ def _edges(vals: List[float]) -> np.ndarray:
 
 
 def _lut_of(colormap: str) -> np.ndarray:
-    """256 x 3 bytes of a matplotlib colormap as the Agg renderer writes them (rounded)."""
+    """256 x 3 bytes of a matplotlib colormap as the Agg renderer writes them (rounded): entry i is the colour of the
+    normalised value i / 256, which for the usual 256-entry maps is the map's own entry i and for a map of fewer
+    colours (tab10, Set1, ...) the colour that value falls on."""
     cmap = plt.get_cmap(colormap)
-    return np.rint(np.asarray(cmap(np.arange(256)))[:, :3] * 255).astype(np.uint8)
+    return np.rint(np.asarray(cmap(np.arange(256) / 256.0))[:, :3] * 255).astype(np.uint8)
 
 
 def generate_heatmap(matrix: np.ndarray, aod_list: List[float], aoa_list: List[float], output_path: str, title: str,
