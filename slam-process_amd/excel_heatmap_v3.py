@@ -7,9 +7,10 @@ map_angles, :286-314 compute_rssi_matrix, :320-368 blur, :374-475 generate_heatm
 GPU through libslamhip.so; matplotlib only draws the figure furniture (axes, colour bar, title, grid)
 around the device-coloured mesh.  There is no CPU implementation behind the compute functions.
 
-What differs from the reference: workbooks are read with the standard library (no openpyxl); RSS
-values must be integers (the device pivot keeps an exact integer sum per cell); at most 64 distinct
-angles per axis.
+What differs from the reference: workbooks are read with the standard library (no openpyxl);
+generate_heatmap colours matrices of up to 256 x 256 cells (the library's axis limit; beams are 0..63,
+so a mapped table has at most 64 angles an axis).  RSS may be any float: whole numbers are summed
+exactly, fractions with pandas' compensated sum in row order.
 """
 from __future__ import annotations
 
@@ -197,21 +198,32 @@ def compute_rssi_matrix(df: pd.DataFrame, logger: Optional[logging.Logger] = Non
     """Mean RSS per (AoD, AoA) over the angles that occur, NaN where a pair never occurs (reference :286-314)."""
     aod_vals = np.unique(df["AoD"].to_numpy(np.float64))
     aoa_vals = np.unique(df["AoA"].to_numpy(np.float64))
-    if len(aod_vals) > 64 or len(aoa_vals) > 64:      # beams are 0..63 (validate_beam_id), so a mapping gives at most 64
-        raise ValueError("more than 64 distinct angles on an axis: beyond the device pivot's grid")
     rss = df["rss"].to_numpy(np.float64)
     r_idx = np.searchsorted(aod_vals, df["AoD"].to_numpy(np.float64))
     c_idx = np.searchsorted(aoa_vals, df["AoA"].to_numpy(np.float64))
-    n_axis = max(len(aod_vals), len(aoa_vals))
-    ident = np.full(64, -1, np.int16)
-    ident[:n_axis] = np.arange(n_axis)
-    if np.all(rss == np.round(rss)) and np.all(np.abs(rss) < 2.0 ** 31):
-        # whole numbers (every capture's RSS): exact integer sums, which is also what pandas' sum comes to
-        _s, _c, mean = ops.pivot_mean(c_idx, r_idx, rss.astype(np.int64), ident, n_axis)
-    else:
-        # fractions (dBm readings): pandas' compensated sum in row order, followed literally on the device
-        _s, _c, mean = ops.pivot_mean_f64(c_idx, r_idx, rss, ident, n_axis)
-    matrix = np.ascontiguousarray(mean[: len(aod_vals), : len(aoa_vals)])
+    ident = np.arange(64, dtype=np.int16)
+    # whole numbers (every capture's RSS): exact integer sums, which is also what pandas' sum comes to; fractions (dBm
+    # readings): pandas' compensated sum in row order, followed literally on the device
+    whole = bool(np.all(rss == np.round(rss)) and np.all(np.abs(rss) < 2.0 ** 31))
+    matrix = np.full((len(aod_vals), len(aoa_vals)), np.nan)
+    # The device pivot works on 64 x 64 index pairs (beams are 0..63, so a mapped table has at most 64 angles an axis and
+    # this loop runs once); a table that was given more angles directly is served 64 x 64 block by block, each row going
+    # to the block its pair of indices lies in, in row order.
+    for br in range(0, len(aod_vals), 64):
+        for bc in range(0, len(aoa_vals), 64):
+            if len(aod_vals) <= 64 and len(aoa_vals) <= 64:
+                rr, cc, vv = r_idx, c_idx, rss
+            else:
+                sel = (r_idx // 64 == br // 64) & (c_idx // 64 == bc // 64)
+                if not sel.any():
+                    continue
+                rr, cc, vv = r_idx[sel] - br, c_idx[sel] - bc, rss[sel]
+            if whole:
+                _s, _c, mean = ops.pivot_mean(cc, rr, vv.astype(np.int64), ident, 64)
+            else:
+                _s, _c, mean = ops.pivot_mean_f64(cc, rr, vv, ident, 64)
+            h, w = min(64, len(aod_vals) - br), min(64, len(aoa_vals) - bc)
+            matrix[br:br + h, bc:bc + w] = mean[:h, :w]
     if logger:
         logger.info(f"RSSI矩阵尺寸: {matrix.shape} (AoD: {len(aod_vals)} x AoA: {len(aoa_vals)})")
     return matrix, aod_vals.tolist(), aoa_vals.tolist()

@@ -1712,3 +1712,27 @@ def test_stages_run_again_report_the_same_counters(mapping, lut):
     assert np.array_equal(st[:, own], first[:, own]) and not st[:, 4:14].any()
     pipe.run(text, stages=STAGE_CORRECT | STAGE_RENDER)
     assert np.array_equal(pipe.stats_host(), first) and torch.equal(pipe.tiles[:F], tiles)
+
+
+@pytest.mark.parametrize("whole", [True, False])
+def test_rssi_matrix_of_a_table_with_more_angles_than_beams(whole):
+    """compute_rssi_matrix takes any table of AoD / AoA / rss (the reference's does, excel_heatmap_v3.py:286-314): with
+    more than 64 distinct angles on an axis the drop-in serves it 64 x 64 block by block on the device.  Checked
+    against the call the reference makes, pandas' pivot_table(mean) reindexed on the sorted angles: equal for whole
+    numbers (exact sums), bit for bit for fractions (compensated sums in row order)."""
+    import pandas as pd
+    import excel_heatmap_v3 as E
+    rng = np.random.default_rng(12 + int(whole))
+    for n_aod, n_aoa, n in ((150, 90, 40000), (65, 64, 3000), (64, 130, 9000), (200, 200, 500)):
+        aod_pool = np.round(np.sort(rng.choice(np.arange(-900, 900), n_aod, replace=False)) * 0.1, 1)
+        aoa_pool = np.round(np.sort(rng.choice(np.arange(-900, 900), n_aoa, replace=False)) * 0.1, 1)
+        rss = rng.integers(15000, 93000, n).astype(np.float64) if whole else np.round(rng.normal(-70, 12, n), 2)
+        df = pd.DataFrame({"AoD": aod_pool[rng.integers(0, n_aod, n)], "AoA": aoa_pool[rng.integers(0, n_aoa, n)], "rss": rss})
+        want = pd.pivot_table(df, index="AoD", columns="AoA", values="rss", aggfunc="mean")
+        aod_w, aoa_w = sorted(set(df["AoD"].tolist())), sorted(set(df["AoA"].tolist()))
+        want = want.reindex(index=aod_w, columns=aoa_w).to_numpy()
+        mat, aod, aoa = E.compute_rssi_matrix(df)
+        assert aod == aod_w and aoa == aoa_w and mat.shape == want.shape
+        assert np.array_equal(np.isnan(mat), np.isnan(want))
+        fin = ~np.isnan(want)
+        assert np.array_equal(mat[fin].view(np.uint64), want[fin].view(np.uint64)), (n_aod, n_aoa)
