@@ -258,9 +258,13 @@ int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t sta
  * travel as a kernel argument); kernel timing is off for the call.  Same batch, same stages, same results.
  * Limits: SLAM_E_CAPACITY when the batch shape needs more scratch than the array holds (one 256 x 4096-record frame
  * needs about 54 MB; several smaller frames fit together), SLAM_E_RANGE for a blur of more than 21 taps
- * (sigma > 3.5).  All calls on one GPU share that GPU's array, whatever their ctx or stream: two calls that overlap
- * in time on one GPU race, and a call may not overlap slam_process_frames_dev output it still needs from the array
- * (tile_cnt / kept_cnt / cells / colmap / rowmap left NULL live there until the next call). */
+ * (sigma > 3.5).  All calls on one GPU share that GPU's array, whatever their ctx, stream or thread: they are ordered.
+ * Each call makes its stream wait for the call issued before it on that GPU (an event per device, created with the
+ * first ctx; the host side of a call runs under a mutex per device), so concurrent callers get the results they would
+ * get alone, one after the other.  Not covered: a call captured into a HIP graph records no event and waits for none
+ * (its replays are ordered by the stream they are launched on; keeping them apart from other users of the array is the
+ * caller's business), and outputs left in the array (tile_cnt / kept_cnt / cells / colmap / rowmap passed as NULL)
+ * live only until the next call on that GPU. */
 #define SLAM_NOALLOC_SCRATCH_BYTES (64u << 20)
 int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
 

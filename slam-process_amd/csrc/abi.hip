@@ -4,6 +4,7 @@
 #include <stdarg.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "pipeline.hpp"
 
@@ -22,14 +23,24 @@ constexpr int NOALLOC_KMAX = 21;                          // blur taps per side 
 constexpr size_t NOALLOC_KERN_BYTES = 4096;               // front of the scratch: the Gaussian weights (21 * 21 doubles)
 static_assert(NOALLOC_KMAX * NOALLOC_KMAX * sizeof(double) <= NOALLOC_KERN_BYTES, "kernel weights fit their piece");
 
+// Calls on the fixed scratch are ordered per device: each waits, on its own stream, for the event the call before it
+// recorded, and the host side of a call (wait, launches, record) runs under the device's mutex, so the record a call
+// waits for is always that of the call issued just before it, whatever ctx, stream or thread issued it.
+static hipEvent_t scratch_done[SCRATCH_MAX_DEVICES];
+static std::mutex scratch_mutex[SCRATCH_MAX_DEVICES];
+static std::mutex scratch_setup_mutex;
+
 static hipError_t resolve_scratch(int device)              // `device` must be the current device
 {
     if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(scratch_setup_mutex);
     if (scratch_ptr[device]) return hipSuccess;
     unsigned char *p = nullptr;
     hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
     if (!p) return hipErrorInvalidSymbol;
+    e = hipEventCreateWithFlags(&scratch_done[device], hipEventDisableTiming);
+    if (e != hipSuccess) return e;
     scratch_ptr[device] = p;
     return hipSuccess;
 }
@@ -960,6 +971,12 @@ extern "C" int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *
     uint8_t *base = scratch_ptr[ctx->device];                 // the device address, never the symbol's name
     double *kern = reinterpret_cast<double *>(base);
     int ks = 1;
+    // One call at a time per device on the array: behind the call before (any ctx, any stream, any thread).  A call
+    // that is being captured into a graph takes no part in this: its replays are ordered by the stream they are
+    // launched on, and keeping them apart from other users of the array is the caller's business.
+    std::lock_guard<std::mutex> order(scratch_mutex[ctx->device]);
+    const bool captured = stream_is_capturing(ctx);
+    if (!captured) SLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, scratch_done[ctx->device], 0));
     const bool timing = ctx->timing;                          // event timers create events: off for this call
     ctx->timing = false;
     int rc = SLAM_OK;
@@ -996,5 +1013,8 @@ extern "C" int slam_process_frames_noalloc_dev(slam_ctx *ctx, const slam_batch *
     }
     if (rc == SLAM_OK) rc = run_batch(ctx, bt, stages, bp, base + NOALLOC_KERN_BYTES, kern, ks);
     ctx->timing = timing;
+    // recorded whatever rc is: kernels of a call that failed half way may still be running on the array
+    if (!captured && hipEventRecord(scratch_done[ctx->device], ctx->stream) != hipSuccess && rc == SLAM_OK)
+        rc = slam_fail(ctx, SLAM_E_HIP, "slam_process_frames_noalloc_dev: hipEventRecord failed");
     return rc;
 }

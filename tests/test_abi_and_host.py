@@ -60,6 +60,37 @@ def test_product_never_imports_the_oracle():
                 assert "slam_oracle" not in src and "liboracle" not in src, os.path.join(dirpath, f)
 
 
+def test_kernel_resources():
+    """The compiler's own report of the library as built: the hot kernels use no scratch (no register spills to
+    memory) and keep the waves per SIMD their design counts on, by registers and by LDS."""
+    from slamhip import build
+    build.build(force=False, verbose=False)               # rebuilds (and rewrites the report) when a source is newer
+    rep = build.read_report()
+    assert len(rep) > 40
+    committed = os.path.join(ROOT, "profiles", "r3_kernel_resources.txt")
+    assert open(committed).read() == open(build.REPORT).read(), "profiles/r3_kernel_resources.txt is not this build's report"
+
+    def waves(k):
+        threads = 1024 if k["kernel"].startswith("k_pivot<") else 256
+        if k["kernel"].startswith("k_frame_fused"):
+            threads = 512
+        by_lds = (160 * 1024 // k["lds"]) * (threads // 64) // 4 if k["lds"] else 8
+        return min(k["waves"], by_lds, 8)
+
+    need = {"k_frame_onepass<0>": 4, "k_frame_onepass<1>": 4,
+            "k_rows_finish<unsigned char, unsigned int, 0, 3>": 6, "k_rows_finish<unsigned char, unsigned int, 1, 3>": 6,
+            "k_rows_finish<unsigned char, unsigned int, 2, 3>": 4, "k_pivot<unsigned char, unsigned int>": 4,
+            "k_raster": 8, "k_bl_sort_small": 6}
+    by_name = {k["kernel"]: k for k in rep}
+    for name, w in need.items():
+        assert name in by_name, name
+        k = by_name[name]
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, (name, k)
+        assert waves(k) >= w, (name, k, waves(k))
+    # no kernel of the library spills vector registers at all
+    assert [k["kernel"] for k in rep if k["scratch"] or k["vgpr_spill"]] == []
+
+
 def test_xlsx_round_trip(tmp_path):
     from slamhip import xlsx
     p = str(tmp_path / "t.xlsx")

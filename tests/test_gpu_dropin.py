@@ -117,6 +117,15 @@ def test_errors_follow_the_reference(tmp_path):
         E.generate_heatmap(np.full((2, 2), np.nan), [0.0, 1.0], [0.0, 1.0], str(tmp_path / "x.png"), "t", use_log=False)
 
 
+def _assert_blur(bl, mat, sigma=1.0, tol=1e-12):
+    """The device's blurred matrix against the oracle's gaussian_blur_nan_aware (excel_heatmap_v3.py:336-368) of the
+    oracle's own mean matrix: same NaN cells, finite cells within tol (relative)."""
+    ob = O.blur_nan_aware(mat, sigma)
+    fin = np.isfinite(ob)
+    assert bl.shape == ob.shape and np.array_equal(np.isfinite(bl), fin)
+    assert np.max(np.abs(bl[fin] - ob[fin]) / np.abs(ob[fin])) <= tol
+
+
 def test_full_size_frames_bit_exact():
     """The benchmark's 256 x 4096 shape, two frames, every integer output against the oracle."""
     import torch
@@ -149,6 +158,7 @@ def test_full_size_frames_bit_exact():
         mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
         full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(f, st)
         assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+        _assert_blur(bl, mat)
         r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=1024, H=1024)
         assert np.array_equal(pipe.frame_tile(f), r["tile"])
         # size-independent property: the tile holds exactly the colours of the cells
@@ -210,6 +220,7 @@ def test_long_sweep_and_wide_frames_bit_exact(shape):
     mat, aod, aoa, so, co = O.pivot_mean(kept_o["ue"], kept_o["bs"], kept_o["rss"], mapping)
     full, bl, aod_g, aoa_g, lo, hi = pipe.frame_matrix(0, st)
     assert np.array_equal(full, np.where(co > 0, so / np.maximum(co, 1), np.nan), equal_nan=True)
+    _assert_blur(bl, mat)
     r = O.render(bl, aod, aoa, lut, use_log=False, blur_sigma=0.0, W=256, H=256)
     assert np.array_equal(pipe.frame_tile(0), r["tile"])
     if shape != (1024, 8192):

@@ -98,3 +98,97 @@ def test_noalloc_entry_point_rejects_what_does_not_fit():
     with pytest.raises(_lib.SlamError) as e:
         small.ctx.check(small.ctx.lib.slam_process_frames_noalloc_dev(small.ctx.h, C.byref(small.bt), 7))
     assert e.value.code == _lib.E_RANGE
+
+
+def _pipe_for(B, N, F, first, tile, sigma=1.0):
+    from slamhip import synth
+    from slamhip.pipeline import FramePipeline, default_mapping, synth_frames, viridis_lut
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    text = synth_frames(F, B, N, first_frame=first)
+    pipe = FramePipeline(F, tl, tile_w=tile[0], tile_h=tile[1], mapping=default_mapping(), lut=viridis_lut(),
+                         blur_sigma=sigma, reserve=False)
+    pipe.set_uniform_layout(F, stride, tl)
+    return pipe, text
+
+
+def test_noalloc_calls_from_two_threads_are_ordered():
+    """Two host threads, a ctx and a stream each, both on the fixed scratch at once: every call's outputs equal what
+    the same call gives when it runs alone (the calls wait for each other on the device)."""
+    import threading
+    import torch
+    shapes = [(64, 1024, 3, 11, (160, 128)), (48, 768, 2, 23, (96, 64))]
+    alone = []
+    for B, N, F, first, tile in shapes:
+        pipe, text = _pipe_for(B, N, F, first, tile)
+        pipe.run(text, noalloc=True)
+        alone.append(_outputs(pipe, F))
+        del pipe, text
+    pipes = [_pipe_for(*s) for s in shapes]
+    streams = [torch.cuda.Stream() for _ in shapes]
+    torch.cuda.synchronize()
+    rounds, errors = 12, []
+    results = [[] for _ in shapes]
+    barrier = threading.Barrier(len(shapes))
+
+    def worker(i):
+        try:
+            pipe, text = pipes[i]
+            F = shapes[i][2]
+            barrier.wait()
+            for r in range(rounds):
+                with torch.cuda.stream(streams[i]):
+                    pipe.tiles.fill_(7)
+                    pipe.run(text, noalloc=True)
+                    # the reads below run on the same stream, i.e. behind this call only: a later call of the other thread
+                    # that did not wait for this one would show in them
+                    snap = dict(stats=pipe.stats.clone(), tiles=pipe.tiles[:F].clone(), kept=pipe.k_bs.clone(),
+                                kept_cnt=pipe.kept_cnt.clone(), cells=pipe.compact[0].clone())
+                results[i].append(snap)
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(shapes))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i, (B, N, F, first, tile) in enumerate(shapes):
+        pipe = pipes[i][0]
+        final = _outputs(pipe, F)
+        _same(alone[i], final, F, ("threads, last round", i))
+        for r, snap in enumerate(results[i]):
+            assert np.array_equal(snap["tiles"].cpu().numpy(), alone[i]["tiles"]), (i, r)
+            assert np.array_equal(snap["cells"].cpu().numpy(), alone[i]["cells"]), (i, r)
+            assert np.array_equal(snap["kept_cnt"].cpu().numpy(), alone[i]["kept_cnt"]), (i, r)
+
+
+def test_noalloc_entry_point_under_graph_capture():
+    """The call captured into a HIP graph (nothing in it allocates, copies from the host or synchronises) and replayed
+    on fresh text: same bytes as the direct call."""
+    import torch
+    B, N, F, tile = 32, 1024, 2, (128, 96)
+    from slamhip import synth
+    from slamhip.pipeline import synth_frames
+    pipe, text = _pipe_for(B, N, F, 3, tile)
+    pipe.run(text, noalloc=True)
+    want_a = _outputs(pipe, F)
+    other = synth_frames(F, B, N, first_frame=77)
+    pipe.run(other, noalloc=True)
+    want_b = _outputs(pipe, F)
+    assert not np.array_equal(want_a["tiles"], want_b["tiles"])
+    buf = text.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.run(buf, noalloc=True)                          # warm-up on the capturing stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        pipe.run(buf, noalloc=True)
+    for src, want in ((text, want_a), (other, want_b), (text, want_a)):
+        buf.copy_(src)
+        pipe.tiles.fill_(9)
+        g.replay()
+        _same(want, _outputs(pipe, F), F, "replay")
