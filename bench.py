@@ -59,6 +59,8 @@ def parse_args():
     p.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short passes over the other shapes")
+    p.add_argument("--fused", type=int, choices=(0, 1), default=None,
+                   help="decode + correction as one fused kernel (1) or as separate kernels (0); default: the library's")
     p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                    help="N>1 process group; gloo (collectives staged through host memory) only to rehearse the "
                         "multi-rank control flow on a box with fewer GPUs than ranks")
@@ -162,6 +164,7 @@ def kernel_accounting(kern, nbytes, valid, kept, tile_bytes, frames_per_launch_o
     counted); kernels that split one job (KERNEL_GROUPS) are priced together."""
     alg = {
         "frame_onepass": 3.0 * nbytes + 11.0 * valid,    # text in, records out
+        "frame_fused": 3.0 * nbytes + 11.0 * valid + 10.0 * kept,      # text in, records and kept rows out
         "tile_groups": 0.5 * valid,                      # 12 bits per 4 entries
         "rows_finish": 10.0 * valid + 10.0 * kept,       # flag, ue, rss, clk in; kept rows out
         "pivot": 6.0 * kept,
@@ -301,7 +304,7 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
     text = synth_frames(n_distinct, B, N, first_frame=rank * n_distinct, device=job.local)
     any_gather = any(m != "none" for m in modes)
     pipe = FramePipeline(F, tl, device=job.local, tile_w=tile, tile_h=tile, mapping=mapping, lut=lut, upscale=upscale,
-                         n_tile_slots=2 * F if tiles_mode else F, n_compact_slots=2 if any_gather else 1)
+                         n_tile_slots=2 * F if tiles_mode else F, n_compact_slots=2 if any_gather else 1, fused=a.fused if a.fused is None else bool(a.fused))
     pipe.set_uniform_layout(F, stride, tl)
     ctx = pipe.ctx
     torch.cuda.synchronize(dev)
@@ -394,7 +397,9 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
     if kern:
         table, roof, ach = kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / max(launches, 1),
                                              B, N, upscale)
+    served = int(((st[:, _lib.STAT_LAYOUT] & _lib.LAYOUT_KEPT_GROUPS) != 0).sum())
     res = dict(value=fps_rank * world, ms_per_step=dt / K * 1e3, F=F, n_distinct=n_distinct, tl=tl, kappa=kappa,
+               fused=pipe.ctx.get_fused(), fused_frames=served,
                alg_frame=alg_frame, fps_rank=fps_rank, kernels=table, roofline=roof, achieved=ach,
                gather_verified=verified, gather_rates=gather_rates if world > 1 else None)
     return res, pipe, text
@@ -410,6 +415,7 @@ def short_config(job, name, B, N, F, K, W, tile, upscale):
                          f"reference admits 64 beams)" if upscale > 1 else ""),
                value=round(res["value"], 2), unit="frames/s", frames_per_step=res["F"], steps=K, warmup=W,
                ms_per_step=round(res["ms_per_step"], 4), kappa_kept_ratio=round(res["kappa"], 4),
+               fused_frames=res["fused_frames"] if res["fused"] else None,
                alg_bytes_per_frame=int(res["alg_frame"]),
                pipeline_alg_GBps=round(res["fps_rank"] * res["alg_frame"] / 1e9, 1),
                pipeline_hbm_frac=round(res["fps_rank"] * res["alg_frame"] / 1e9 / HBM_PEAK_GBS, 4),
@@ -487,6 +493,8 @@ def main():
                                f"{F} frames/step, {res['n_distinct']} distinct frames resident in HBM per GPU, "
                                f"tile {a.tile}x{a.tile} RGBA" + (f", beam table up-scaled x{a.upscale}" if a.upscale > 1 else ""),
                    "frames_per_step": F, "beams": B, "samples": N,
+                   "decode_correct": ("one fused kernel" if res["fused"] else "separate kernels") +
+                                     (f" ({res['fused_frames']} of {F} frames of the last batch served by it)" if res["fused"] else ""),
                    "parallelism": f"frames sharded over {world} GPU(s)" +
                                   {"none": "", "tiles": ", 4 MiB tiles gathered to rank 0 every step (RCCL)",
                                    "compact": ", tiles gathered to rank 0 every step in compact form (cell colours + "

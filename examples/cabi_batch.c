@@ -142,7 +142,7 @@ int main(void)
     uint8_t *tile_a = to_host(a.tile, (size_t)F * W * H * 4);
     for (int f = 0; f < F; f++) {
         const uint32_t *s = st + f * SLAM_STAT_WORDS;
-        CHECK(s[SLAM_STAT_NOT_STRICT] == 0 && s[SLAM_STAT_TWO_PASS] == 0);
+        CHECK(s[SLAM_STAT_NOT_STRICT] == 0 && (s[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_TWO_PASS) == 0);
         CHECK(s[SLAM_STAT_NBYTES] == (tl + 1) / 3 - 1);                       /* the text starts with the 3-byte mark */
         CHECK(s[SLAM_STAT_VALID] > B * N * 9 / 10 && s[SLAM_STAT_VALID] <= B * N);
         CHECK(s[SLAM_STAT_GROUPS] == B);                                      /* one group per sweep (UE falls back) */
@@ -150,7 +150,8 @@ int main(void)
         CHECK(s[SLAM_STAT_ALLNAN] == 0 && s[SLAM_STAT_N_AOD] > 0 && s[SLAM_STAT_N_AOA] == NA);
         uint32_t rows = 0, kept = 0;
         for (uint32_t t = 0; t < T; t++) rows += tc[f * T + t];
-        for (uint32_t k = 0; k < KB; k++) kept += kc[f * KB + k];
+        const uint32_t ku = (s[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
+        for (uint32_t k = 0; k < (s[SLAM_STAT_ROW_SLOTS] + ku - 1) / ku; k++) kept += kc[f * KB + k];   /* the frame's blocks */
         CHECK(rows == s[SLAM_STAT_VALID] && kept == s[SLAM_STAT_KEPT]);       /* the slots' counts add up to the counters */
         size_t opaque = 0, clear = 0;                   /* a cell with no finite value within the blur's reach stays transparent */
         for (size_t px = 0; px < (size_t)W * H; px++) {
@@ -193,9 +194,11 @@ int main(void)
         uint32_t *d_kck = to_host(a.kclk, (size_t)row_cap * 4);
         i = 0;
         same = 1;
-        for (uint32_t blk = 0; blk < KB; blk++)
+        /* blocks of the corrected-row arrays: SLAM_KEPT_BLOCK entries, or 16 tiles' entries where the fused kernel served the frame */
+        const uint32_t unit = (st[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
+        for (uint32_t blk = 0; blk < KB && (size_t)blk * unit < row_cap; blk++)
             for (uint32_t k = 0; k < kc[blk]; k++, i++) {
-                const size_t e = (size_t)blk * SLAM_KEPT_BLOCK + k;
+                const size_t e = (size_t)blk * unit + k;
                 same &= (int32_t)d_kbs[e] == k4[1][i] && (int32_t)d_kck[e] == k4[3][i];
             }
         CHECK(i == nk && same);
@@ -259,7 +262,7 @@ int main(void)
         int seen_framing = 0;
         for (int i = 0; i < n; i++) {
             printf("  %-20s %u launch(es) %.3f ms\n", names + 32 * i, launches[i], ms[i]);
-            seen_framing |= strcmp(names + 32 * i, "frame_onepass") == 0;
+            seen_framing |= strcmp(names + 32 * i, "frame_onepass") == 0 || strcmp(names + 32 * i, "frame_fused") == 0;
         }
         CHECK(seen_framing);
         CHECK(slam_timing_reset(ctx) == SLAM_OK);

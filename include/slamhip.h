@@ -51,6 +51,10 @@ int slam_use_own_stream(slam_ctx *ctx);
 int slam_sync(slam_ctx *ctx);
 const char *slam_last_error(slam_ctx *ctx);
 const char *slam_version(void);
+/* Revision of this binary interface (struct layouts, argument lists, buffer layouts): a binding compares it with
+ * the SLAM_ABI_REVISION it was written against before the first call. */
+#define SLAM_ABI_REVISION 3
+int slam_abi_revision(void);
 
 /* ---- a1: hex text -> bytes ---------------------------------------------------------------
  * Replaces _read_bytes (serial_hex_to_excel_v3.py:18-36, regex :16): UTF-8 decode with
@@ -185,10 +189,12 @@ typedef struct slam_batch {
      * [t*SLAM_TILE_BYTES, (t+1)*SLAM_TILE_BYTES) of frame f, in order, occupy entries
      * [t*SLAM_TILE_SLOTS, t*SLAM_TILE_SLOTS + tile_cnt_dev[f*T + t]) with T = slam_row_tiles(max_text_len,
      * src_is_bytes); the other entries of a tile are unused.  Concatenating the tiles' used entries gives
-     * the reference's record list.  Corrected rows (kept_*) use the same scheme over blocks of
-     * SLAM_KEPT_BLOCK entries: the rows kept among entries [b*SLAM_KEPT_BLOCK, (b+1)*SLAM_KEPT_BLOCK) of the
-     * decoded arrays sit, in order, at the front of the same entries of the kept arrays, kept_cnt_dev[f*KB + b]
-     * of them, KB = ceil(row_cap / SLAM_KEPT_BLOCK). */
+     * the reference's record list.  Corrected rows (kept_*) use the same scheme over blocks of U entries:
+     * the rows kept among entries [b*U, (b+1)*U) of the decoded arrays sit, in order, at the front of the same
+     * entries of the kept arrays, kept_cnt_dev[f*KB + b] of them, KB = ceil(row_cap / SLAM_KEPT_BLOCK).  U is a
+     * property of the frame: SLAM_KEPT_BLOCK, or SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS when bit
+     * SLAM_LAYOUT_KEPT_GROUPS of the frame's SLAM_STAT_LAYOUT word is set (frames the fused decode + correct
+     * kernel served, see slam_set_fused). */
     uint32_t row_cap;             /* multiple of 16, >= T * SLAM_TILE_SLOTS                       */
     uint8_t *flag_dev, *ue_dev, *bs_dev;        /* decoded records                               */
     uint32_t *rss_dev, *clk_dev;
@@ -218,7 +224,8 @@ size_t slam_batch_sizeof(void);
 
 #define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
 #define SLAM_TILE_SLOTS     276   /* entries reserved per tile in the decoded-record arrays        */
-#define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays                 */
+#define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays ...            */
+#define SLAM_KEPT_GROUP_TILES 16  /* ... or this many tiles' entries per block (SLAM_LAYOUT_KEPT_GROUPS) */
 /* Tiles per frame for frames of up to max_text_len text bytes (or data bytes when src_is_bytes). */
 uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 
@@ -239,7 +246,9 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 #define SLAM_STAT_VMAX_LO    12
 #define SLAM_STAT_VMAX_HI    13
 #define SLAM_STAT_ROW_SLOTS  14   /* entries of the decoded-record arrays this frame spans         */
-#define SLAM_STAT_TWO_PASS   15   /* 1 = decoded by the two-pass kernels (entries then dense)      */
+#define SLAM_STAT_LAYOUT     15   /* bits: how the frame's row arrays are laid out                  */
+#define SLAM_LAYOUT_TWO_PASS     1u  /* decoded by the two-pass kernels: entries are dense (all tiles full but the last) */
+#define SLAM_LAYOUT_KEPT_GROUPS  2u  /* corrected rows are slotted per SLAM_KEPT_GROUP_TILES tiles, not per SLAM_KEPT_BLOCK */
 
 /* Replaces, per frame, the chain main() -> _read_bytes -> _parse_groups
  * (serial_hex_to_excel_v3.py:153-154), process_excel_filtered's data path
@@ -248,6 +257,17 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
  * stages: bit 0 decode, bit 1 correct, bit 2 pivot+blur+raster (later stages need earlier ones; a stage may be run
  * again on the same buffers, its counters are set, not added to; the decode stage starts a frame's stats afresh). */
 int slam_process_frames_dev(slam_ctx *ctx, const slam_batch *batch, uint32_t stages);
+
+/* How slam_process_frames_dev / _noalloc_dev run a call that asks for decode and correction together: 0 = two
+ * kernels (records to memory, then read again by the correction), 1 = one fused kernel that corrects a workgroup's
+ * rows while they are still on chip (frames it cannot finish -- a sweep of more than 256 baselines, more than 7
+ * sweep starts within 16 tiles, a tolerance of half a cycle or more, a cycle of 2^24 or more ... -- are handed to
+ * the separate kernels inside the same call).  Same records, same corrected rows, same counters either way; only
+ * the block size of the corrected-row arrays differs per frame (SLAM_STAT_LAYOUT).  A new ctx takes its setting from
+ * the environment variable SLAMHIP_FUSED (0 / 1) if set, else the library's default.  No counterpart in the
+ * reference, which corrects a table with Python loops (bs_beam_correction.py:140-178). */
+int slam_set_fused(slam_ctx *ctx, int mode);
+int slam_get_fused(slam_ctx *ctx);
 
 /* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference, which has no device memory to manage.  Where

@@ -2,6 +2,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -59,7 +60,13 @@ int slam_fail(slam_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-extern "C" const char *slam_version(void) { return "slamhip 0.1 (gfx950)"; }
+extern "C" const char *slam_version(void) { return "slamhip 0.3 (gfx950)"; }
+extern "C" int slam_abi_revision(void) { return SLAM_ABI_REVISION; }
+
+// the library's default for slam_set_fused, unless the environment says otherwise
+#ifndef SLAM_FUSED_DEFAULT
+#define SLAM_FUSED_DEFAULT 1
+#endif
 
 extern "C" int slam_ctx_create(int device, slam_ctx **out)
 {
@@ -72,6 +79,9 @@ extern "C" int slam_ctx_create(int device, slam_ctx **out)
     if (device < SCRATCH_MAX_DEVICES && resolve_scratch(device) != hipSuccess) return SLAM_E_HIP;
     slam_ctx *c = new slam_ctx();
     c->device = device;
+    const char *fe = getenv("SLAMHIP_FUSED"), *tp = getenv("SLAMHIP_FORCE_TWO_PASS");
+    c->fused = fe && (fe[0] == '0' || fe[0] == '1') ? fe[0] - '0' : SLAM_FUSED_DEFAULT;
+    c->force_two_pass = tp && tp[0] == '1';
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SLAM_E_HIP; }
     c->stream = c->own_stream;
     if (hipHostMalloc((void **)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
@@ -111,6 +121,16 @@ extern "C" int slam_use_own_stream(slam_ctx *ctx)
     ctx->stream = ctx->own_stream;
     return SLAM_OK;
 }
+
+extern "C" int slam_set_fused(slam_ctx *ctx, int mode)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    if (mode != 0 && mode != 1) return slam_fail(ctx, SLAM_E_INVALID, "slam_set_fused: mode must be 0 or 1");
+    ctx->fused = mode;
+    return SLAM_OK;
+}
+
+extern "C" int slam_get_fused(slam_ctx *ctx) { return ctx ? ctx->fused : SLAM_E_INVALID; }
 
 extern "C" int slam_sync(slam_ctx *ctx)
 {
@@ -787,8 +807,9 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[6], cw[16], rw[12], tc, tb[3];
+    size_t fw[6], cw[16], rw[12], tc, tb[3], zw[5];
     uint32_t nt_max, st_max, bl_cap;
+    int32_t n_axis;             // the batch's, or 64 where the batch leaves it unset (no render stage)
     size_t total;
 };
 
@@ -813,9 +834,12 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
     bp.tb[2] = p.add((size_t)bt->n_frames * bp.st_max * BL_PAY_CAP * sizeof(unsigned long long));
     bp.nt_max = frame_tiles_for(bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, bt->max_text_len);
     bp.bl_cap = correct_ws::default_bl_cap(bt->row_cap);
+    // sized before the stages are known: a batch without a render stage may leave n_axis unset
+    bp.n_axis = bt->n_axis >= 1 && bt->n_axis <= SLAM_MAX_AXIS ? bt->n_axis : SMALL_AXIS;
     frame_ws::plan(p, bt->n_frames, bp.nt_max, bp.fw);
     correct_ws::plan(p, bt->n_frames, bt->row_cap, bp.bl_cap, bp.cw);
-    render_ws::plan(p, bt->n_frames, bt->tile_w, bt->tile_h, bt->n_axis, bp.rw);
+    render_ws::plan(p, bt->n_frames, bt->tile_w, bt->tile_h, bp.n_axis, bp.rw);
+    fused_ws::plan(p, bt->n_frames, bp.st_max, bp.zw);
     bp.total = p.total;
     return SLAM_OK;
 }
@@ -876,7 +900,7 @@ static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const
     correct_ws cws;
     cws.bind(b, bp.cw, bp.bl_cap);
     render_ws rws;
-    rws.bind(b, bp.rw, bt->n_axis);
+    rws.bind(b, bp.rw, bp.n_axis);
     if (bt->cells_dev) rws.cells = bt->cells_dev;
     if (bt->colmap_dev) rws.colmap = bt->colmap_dev;
     if (bt->rowmap_dev) rws.rowmap = bt->rowmap_dev;
@@ -891,24 +915,36 @@ static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const
     if (stages & 2u) rows.bits = tbits;          // the framing pass leaves the correction's per-tile bits
     const uint32_t kept_stride = (bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : cws.rt_nkept;
+    correct_params prm;
+    if (stages & 2u) {
+        prm.set_cycle(bt->cycle);
+        prm.tol = bt->tol;
+        prm.mod_base = bt->mod_base;
+    }
+    kept_out_t<uint8_t, uint32_t> kout{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev, kept_cnt, kept_stride};
+    // decode and correction asked for together: one fused kernel, the separate correction kernels only for the frames it flags
+    const bool fused = ctx->fused && (stages & 3u) == 3u && fused_supported(prm);
+    fused_args fz;
+    if (fused) {
+        fz.fw.bind(b, bp.zw, bp.st_max);
+        fz.prm = prm;
+        fz.prm.small_tol = 1;
+        fz.kout = kout;
+        rows.bits = tile_bits();                 // the fused kernel keeps the per-tile bits on chip
+        cws.gate = fz.fw.redo;
+    }
     if (stages & 1u) {
         SLAM_TRY(slam_zero_async(ctx, bt->stats_dev, (size_t)F * SLAM_STAT_WORDS * 4));
         frame_src fs{bt->text_dev, bt->text_off_dev, bt->text_len_dev, nullptr, 0, nullptr};
         SLAM_TRY(frame_decode(ctx, bt->src_is_bytes ? SRC_RAW : SRC_TEXT3, fs, F, bt->max_text_len, fws, bp.nt_max,
-                              rows, bt->stats_dev));
+                              rows, bt->stats_dev, fused ? &fz : nullptr, ctx->force_two_pass));
     }
     if (stages & 2u) {
         rows_in_t<uint8_t, uint32_t> in{bt->flag_dev, bt->ue_dev, bt->bs_dev, bt->rss_dev, bt->clk_dev, bt->row_cap,
                                         tile_cnt, bp.st_max};
         in.bits = tbits;
-        in.bits_fresh = (stages & 1u) ? 1 : 0;
-        kept_out_t<uint8_t, uint32_t> out{bt->kept_ue_dev, bt->kept_bs_dev, bt->kept_rss_dev, bt->kept_clk_dev,
-                                          kept_cnt, kept_stride};
-        correct_params prm;
-        prm.set_cycle(bt->cycle);
-        prm.tol = bt->tol;
-        prm.mod_base = bt->mod_base;
-        SLAM_TRY((correct_rows<uint8_t, uint32_t>(ctx, in, F, cws, prm, out, nullptr, bt->stats_dev)));
+        in.bits_fresh = (stages & 1u) && !fused ? 1 : 0;
+        SLAM_TRY((correct_rows<uint8_t, uint32_t>(ctx, in, F, cws, prm, kout, nullptr, bt->stats_dev)));
     }
     if (stages & 4u) {
         render_params rp{bt->beam_to_axis_dev, bt->axis_angle_dev, bt->n_axis, bt->blur_sigma, bt->use_log,

@@ -36,6 +36,10 @@ struct slam_ctx {
     double *kern_dev = nullptr;
     double kern_sigma = 0.0;
     int kern_size = 0;
+    // batched calls: decode + correction as one fused kernel (slam_set_fused); test hook: every frame through the
+    // two-pass framing kernels (environment variable SLAMHIP_FORCE_TWO_PASS=1 when the ctx is created)
+    int fused = 0;
+    int force_two_pass = 0;
     // optional per-kernel timing
     bool timing = false;
     std::vector<slam_timer_slot> timers;

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "pipeline.hpp"
+#include "correct_device.hpp"
 
 namespace {
 
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(256) void k_rows_summarize(rows_in_t<T8, T32> in, u
 __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, uint32_t rt_max, uint32_t *stats,
                                                      int stat_a, int stat_b, int keep_stat_b,
                                                      uint32_t *grp_row, uint32_t *grp_bl, uint32_t grp_stride,
-                                                     uint32_t unit)
+                                                     uint32_t unit, const uint32_t *gate)
 {
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    if (gate && !gate[f]) return;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     const uint32_t nt = (n + unit - 1) / unit;          // counts are per `unit` entries
     uint32_t ca = 0, cb = 0;
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, ui
             else stats[f * SLAM_STAT_WORDS + stat_b] = cb;
         }
         if (grp_row) {
+            // the kernels that follow slot the kept rows per ROWS_PER_BLOCK entries, whatever an earlier call left
+            stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] &= ~SLAM_LAYOUT_KEPT_GROUPS;
             stats[f * SLAM_STAT_WORDS + SLAM_STAT_KEPT] = 0;       // accumulated by the fused correction kernel
             grp_row[(size_t)f * grp_stride + ca] = n;
             grp_bl[(size_t)f * grp_stride + ca] = nbl;
@@ -251,14 +255,15 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
 // of a frame the framing fallback decoded (all == 0: only those, and tiles the framing kernel flagged), or for
 // every tile (all == 1).  One wave per tile, one entry per lane and pass.
 template <typename T8, typename T32>
-__global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats)
+__global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats, const uint32_t *gate)
 {
     const uint32_t f = blockIdx.y, lane = lane_id();
+    if (gate && !gate[f]) return;
     const frame_span sp = span_of(in, f, stats);
     const uint32_t nt = sp.n / SLOT_ROWS;                           // tiles the frame spans
     // every lane looks at one tile; the wave then works through the tiles that need it, one at a time
     const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
-    const bool whole = all || stats[f * SLAM_STAT_WORDS + SLAM_STAT_TWO_PASS];
+    const bool whole = all || (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_TWO_PASS);
     const bool mine = tl < nt && (whole || (in.bits.nbase[(size_t)f * in.bits.stride + tl] & TILE_NEEDS_BITS));
     uint64_t todo = __ballot(mine);
     const size_t fb = (size_t)f * in.row_cap;
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(256) void k_tile_groups(rows_in_t<T8, T32> in, corr
 {
     constexpr uint32_t NG = SLOT_ROWS / 4;                  // 69 four-entry groups per tile
     const uint32_t f = blockIdx.y, lane = lane_id();
+    if (ws.gate && !ws.gate[f]) return;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     const uint32_t nt = n / SLOT_ROWS;
     const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
@@ -386,18 +392,6 @@ __global__ __launch_bounds__(256) void k_tile_groups(rows_in_t<T8, T32> in, corr
     }
 }
 
-// floor(n / cycle) and n mod cycle for n = clk + bias >= 0 (bias is a multiple of cycle, so quotient
-// differences and remainders are those of clk itself).  Division by the launch-constant cycle is a
-// multiply-high with a host-computed magic number (exact for every 32-bit n).
-__device__ __forceinline__ void phase_of(int32_t clk, const correct_params &p, uint32_t *q, uint32_t *r)
-{
-    const uint32_t n = (uint32_t)clk + p.bias;
-    const uint32_t hi = __umulhi(p.div_m, n);
-    const uint32_t qq = (hi + ((n - hi) >> p.div_s1)) >> p.div_s2;
-    *q = qq;
-    *r = n - qq * (uint32_t)p.cycle;
-}
-
 // Baseline j (row order) of frame f out of the per-tile lists; T0..T1 are the tiles of the rows of its group.
 __device__ __forceinline__ unsigned long long baseline_from_tiles(const tile_bits &bits, uint32_t f, uint32_t j,
                                                                   uint32_t T0, uint32_t T1)
@@ -415,46 +409,6 @@ constexpr uint32_t WAVE_SORT_MAX = 64;      // groups of up to this many baselin
 constexpr uint32_t MID_SORT_MAX = 256;      // ... and up to this many by one wave in its own piece of LDS
 constexpr uint32_t MID_TAB_CAP = 512;       // phase tables below this length fit the LDS of k_rows_finish's mid build
 
-// LDS written by some lanes of a wave and read by others of the SAME wave: the hardware runs a wave's LDS
-// operations in order, so only the compiler has to be told not to move them across this point.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Bitonic sort of 64 * E dword keys held E per lane (element i = lane + 64 e sits in kv[e] of lane i % 64): stages
-// whose partner is less than 64 elements away exchange across lanes, the others compare registers of one lane.
-template <int E>
-__device__ __forceinline__ void wave_sort_regs(uint32_t (&kv)[4], uint32_t lane)
-{
-#pragma unroll
-    for (uint32_t k = 2; k <= 64u * E; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const uint32_t je = j >> 6;
-#pragma unroll
-                for (uint32_t e = 0; e < (uint32_t)E; e++) {
-                    if (e & je) continue;
-                    const uint32_t a = kv[e], b = kv[e | je], lo = min(a, b), hi = max(a, b);
-                    const bool asc = ((64u * e) & k) == 0;
-                    kv[e] = asc ? lo : hi;
-                    kv[e | je] = asc ? hi : lo;
-                }
-            } else {
-#pragma unroll
-                for (uint32_t e = 0; e < (uint32_t)E; e++) {
-                    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ j) << 2), (int)kv[e]);
-                    const bool take_min = (((lane + 64u * e) & k) == 0) == ((lane & j) == 0);
-                    kv[e] = take_min ? min(kv[e], other) : max(kv[e], other);
-                }
-            }
-        }
-    }
-}
-
 // Groups with at most 64 baselines, one wave per group: bitonic sort of (phase, index) across the lanes with lane
 // exchanges, no LDS and no barriers.  Groups of 65 .. 256 baselines: still one wave per group, the network runs
 // over the wave's own piece of LDS (two or four elements per lane and stage), again without block barriers.
@@ -466,6 +420,7 @@ __global__ __launch_bounds__(256) void k_bl_sort_small(correct_ws ws, uint32_t r
     __shared__ uint32_t mid_q[4][MID_SORT_MAX], mid_bs[4][MID_SORT_MAX];
     __shared__ uint32_t wg_flags;                        // the frame's flag bits this workgroup found, one atomic at the end
     const uint32_t f = blockIdx.y, lane = lane_id();
+    if (ws.gate && !ws.gate[f]) return;
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
     const bool wide_cycle = (uint32_t)prm.cycle >= (1u << 24);          // phase and index do not fit one dword
     uint32_t my_flags = 0;
@@ -683,6 +638,7 @@ __global__ __launch_bounds__(256) void k_bl_sort(correct_ws ws, uint32_t row_cap
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ uint32_t sh[17];
     const uint32_t f = blockIdx.y, tid = threadIdx.x;
+    if (ws.gate && !ws.gate[f]) return;
     if (bits.pay && skip_upto >= MID_SORT_MAX && !(ws.rt_nbase[f] & 4u)) return;    // k_bl_sort_small saw no group for this kernel
     const uint32_t G = stats[f * SLAM_STAT_WORDS + SLAM_STAT_GROUPS];
     const size_t gs = (size_t)f * (row_cap + 1);
@@ -1050,6 +1006,7 @@ __global__ __launch_bounds__(256) void k_rows_finish(rows_in_t<T8, T32> in, uint
     __shared__ __attribute__((aligned(16))) T32 k_rs[ROWS_PER_BLOCK], k_ck[ROWS_PER_BLOCK];   // kept rows of a block, packed
     __shared__ __attribute__((aligned(16))) T8 k_ue[ROWS_PER_BLOCK], k_bs[ROWS_PER_BLOCK];
     const uint32_t f = blockIdx.y, bx = blockIdx.x, tile0 = bx * TPB, tid = threadIdx.x;
+    if (ws.gate && !ws.gate[f]) return;
     bool only_deferred = false;                          // full build: serve only the blocks of workgroups that deferred
     if (defer) {
         // bit 0: a group above 64 baselines; bit 1: a workgroup deferred; bit 3: a table of MID_TAB_CAP phases or more
@@ -1358,7 +1315,9 @@ __global__ __launch_bounds__(256) void k_kept_total(uint32_t F, const uint32_t *
     const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
     if (f >= F) return;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
-    const uint32_t nblk = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    // blocks of ROWS_PER_BLOCK entries, or of a fused workgroup's entries where the fused kernel served the frame
+    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? (uint32_t)FUSED_ENTRIES : (uint32_t)ROWS_PER_BLOCK;
+    const uint32_t nblk = (n + unit - 1) / unit;
     uint32_t k = 0;
     for (uint32_t b = lane; b < nblk; b += 64) k += kept_cnt[(size_t)f * kept_stride + b];
     k = wave_sum(k);
@@ -1446,10 +1405,10 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         correct_ws w2 = ws;
         w2.rmask = in.bits.rmask;
         SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), dim3((st_max + 255) / 256, F), block, in,
-                    in.bits_fresh ? 0 : 1, stats);
+                    in.bits_fresh ? 0 : 1, stats, ws.gate);
         SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), in.bits.nbound, in.bits.nbase, st_max, stats,
                     (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, 0, ws.grp_row, ws.grp_bl, in.row_cap + 1,
-                    (uint32_t)SLOT_ROWS);
+                    (uint32_t)SLOT_ROWS, ws.gate);
         SLAM_LAUNCH(ctx, "tile_groups", (k_tile_groups<T8, T32>), dim3((st_max + 255) / 256, F), block, in, w2, rt_max,
                     ws.rt_nbound, stats);
         // 64 workgroups a frame (four groups per wave at 1024 groups): 128, 256 and 512 measured 10 - 15 % slower
@@ -1476,7 +1435,7 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
                 ws.rt_nbase, ws.rmask, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nbound, ws.rt_nbase, rt_max, stats,
                 (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, keep_bl, ws.grp_row, ws.grp_bl, in.row_cap + 1,
-                (uint32_t)ROWS_PER_BLOCK);
+                (uint32_t)ROWS_PER_BLOCK, (const uint32_t *)nullptr);
     SLAM_LAUNCH(ctx, "rows_groups", (k_rows_groups<T8, T32>), grid, block, in, rt_max, ws.rt_nbound,
                 ws.rt_nbase, ws, gid_out, stats);
     SLAM_LAUNCH(ctx, "bl_sort_small", k_bl_sort_small, dim3(F <= 8 ? 256 : 64, F), dim3(256), ws, in.row_cap, prm, stats,
@@ -1494,7 +1453,8 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
     SLAM_LAUNCH(ctx, "rows_correct", (k_rows_correct<T8, T32, TC>), grid, block, in, rt_max, ws.rt_nbound, ws,
                 corr, prm_k, ws.rt_nkept, stats);
     SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), ws.rt_nkept, (uint32_t *)nullptr, rt_max, stats,
-                (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ROWS_PER_BLOCK);
+                (int)SLAM_STAT_KEPT, 0, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t)ROWS_PER_BLOCK,
+                (const uint32_t *)nullptr);
     if (out.ue) {
         SLAM_LAUNCH(ctx, "rows_emit_kept", (k_rows_emit_kept<T8, T32, TC>), grid, block, in, rt_max, corr,
                     ws.rt_nkept, out, stats);

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
     const uint32_t n = stats[f * SLAM_STAT_WORDS + stat_word];
     const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
     if (r0 >= n) return;
+    // slotted rows: per ROWS_PER_BLOCK entries, or per fused workgroup where the fused kernel served the frame
+    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? (uint32_t)FUSED_ENTRIES : (uint32_t)ROWS_PER_BLOCK;
     const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
     for (int i = tid; i < N_BEAMS * LSTRIDE; i += 1024) acc[i] = 0;
     if (tid < N_BEAMS) b2a[tid] = beam_to_axis[tid];
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
             if (i0 >= r1) continue;
             lim[h] = r1;                       // slotted rows: only the front of each block of entries is used
             if (slot_cnt) {
-                const uint32_t T = i0 / ROWS_PER_BLOCK;
-                lim[h] = min(r1, T * ROWS_PER_BLOCK + slot_cnt[(size_t)f * slot_stride + T]);
+                const uint32_t T = i0 / unit;
+                lim[h] = min(r1, T * unit + slot_cnt[(size_t)f * slot_stride + T]);
             }
             if (i0 >= lim[h]) continue;
             u[h] = *reinterpret_cast<const V8 *>(ue + fb + i0);

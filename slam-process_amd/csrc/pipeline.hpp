@@ -79,8 +79,10 @@ struct rows_out {
 // out.slot_cnt == nullptr: two passes, dense rows.  Otherwise one pass over the source into the slotted layout
 // (frames whose look-behind run does not pin the scan position are redone by the two-pass kernels and
 // described as full slots); stats also gets ROW_SLOTS and TWO_PASS.
+struct fused_args;
 int frame_decode(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t max_src_len,
-                 const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats);
+                 const frame_ws &ws, uint32_t nt_max, const rows_out &out, uint32_t *stats,
+                 const fused_args *fused = nullptr, int force_two_pass = 0);
 uint32_t frame_tiles_for(int mode, uint32_t max_src_len);
 uint32_t slot_tiles_for(int mode, uint32_t max_src_len);
 // After a dense (two-pass) frame_decode of the same source: data-byte indices of the discarded flag bytes, in scan
@@ -125,6 +127,7 @@ struct correct_ws {
     uint16_t *rmask;                             // [F * row_cap / 4] per 4 entries: group-start bits | baseline bits << 4 | row bits << 8 | FLAG == 1 bits << 12
     uint32_t *tmp_a, *tmp_b;                     // [F * bl_cap] scratch of the large-group sort
     uint32_t *defer;                             // [F * rt_max] workgroups of k_rows_finish left to its full build
+    const uint32_t *gate = nullptr;              // [F] or null: serve only the frames whose word is nonzero (fused_ws::redo)
     uint32_t bl_cap;                             // baselines per frame the arrays can hold
     static uint32_t default_bl_cap(uint32_t row_cap) { return row_cap / 2 + 16; }
     static void plan(ws_plan &p, uint32_t F, uint32_t row_cap, uint32_t bl_cap, size_t off[16]);
@@ -145,6 +148,40 @@ template <typename T8, typename T32>
 int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const correct_ws &ws,
                  const correct_params &prm, const kept_out_t<T8, T32> &out, int32_t *gid_out,
                  uint32_t *stats);
+
+// ---- fused decode + correction -------------------------------------------------------------------
+// One kernel takes text to records AND corrected rows: a workgroup decodes FUSED_TILES consecutive framing tiles,
+// keeps their rows in LDS, exchanges the baselines of the sweeps that cross its borders with the neighbouring
+// workgroups (published through `pub`, signalled through `flag`) and corrects its rows there.  Kept rows of such a
+// frame are slotted per workgroup: the rows kept among entries [w*FUSED_ENTRIES, (w+1)*FUSED_ENTRIES) sit at the
+// front of the same entries, kept slot_cnt[f*slot_stride + w] of them.  A frame the kernel cannot finish (see
+// k_fused.hip) is flagged in `fail` and corrected by the separate kernels, which `redo` gates.
+constexpr int FUSED_TILES = SLAM_KEPT_GROUP_TILES;
+constexpr int FUSED_ENTRIES = FUSED_TILES * SLOT_ROWS;
+constexpr int FUSED_PUB_WORDS = 256;             // 8-byte words a workgroup publishes: header + baselines of its two border sweeps
+constexpr int FUSED_CNT_WORDS = 8;               // per workgroup: valid, discarded, groups, baselines, kept
+struct fused_ws {
+    uint32_t *flag = nullptr;                    // [F * wg_stride] 1 = published (zeroed before every launch)
+    unsigned long long *pub = nullptr;           // [F * wg_stride * FUSED_PUB_WORDS]
+    uint32_t *wg_cnt = nullptr;                  // [F * wg_stride * FUSED_CNT_WORDS]
+    uint32_t *fail = nullptr;                    // [F] nonzero: the fused kernel gave the frame up (zeroed before every launch)
+    uint32_t *redo = nullptr;                    // [F] nonzero: the separate correction kernels serve the frame
+    uint32_t wg_stride = 0;
+    static uint32_t wgs_for(uint32_t st_max) { return (st_max + FUSED_TILES - 1) / FUSED_TILES; }
+    static void plan(ws_plan &p, uint32_t F, uint32_t st_max, size_t off[5]);
+    void bind(uint8_t *base, const size_t off[5], uint32_t st_max);
+};
+bool fused_supported(const correct_params &prm);
+struct fused_args {                              // what frame_decode needs to run the fused kernel instead of k_frame_onepass
+    fused_ws fw;
+    correct_params prm;
+    kept_out_t<uint8_t, uint32_t> kout;
+};
+// the fused kernel over F frames (grid: workgroups of FUSED_TILES tiles x frames), and the per-frame wrap-up after the
+// two-pass kernels have redone what it flagged: counters, layout bits, fw.redo
+int fused_launch(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint32_t st_max, const rows_out &out,
+                 const fused_args &fz, uint32_t *stats);
+int fused_finish_launch(slam_ctx *ctx, int mode, uint32_t F, const fused_args &fz, uint32_t *stats);
 
 // ---- pivot / blur / raster ---------------------------------------------------------------------
 constexpr int SMALL_AXIS = 64;          // axis tables up to here: one workgroup per frame, grids in LDS (k_frame_matrix)

@@ -19,8 +19,15 @@ OK, E_INVALID, E_HIP, E_CAPACITY, E_EMPTY, E_ALLNAN, E_RANGE, E_LIMITS = 0, -1, 
 STAT_WORDS = 16
 (STAT_NBYTES, STAT_NOT_STRICT, STAT_VALID, STAT_DISCARDED, STAT_GROUPS, STAT_BASELINES, STAT_KEPT,
  STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI,
- STAT_ROW_SLOTS, STAT_TWO_PASS) = range(16)
-TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
+ STAT_ROW_SLOTS, STAT_LAYOUT) = range(16)
+LAYOUT_TWO_PASS, LAYOUT_KEPT_GROUPS = 1, 2
+TILE_BYTES, TILE_SLOTS, KEPT_BLOCK, KEPT_GROUP_TILES = 3024, 276, 1024, 16
+ABI_REVISION = 3                      # SLAM_ABI_REVISION of the header this binding was written against
+
+
+def kept_unit(layout_word: int) -> int:
+    """Entries per block of a frame's corrected-row arrays, from its SLAM_STAT_LAYOUT word."""
+    return KEPT_GROUP_TILES * TILE_SLOTS if int(layout_word) & LAYOUT_KEPT_GROUPS else KEPT_BLOCK
 NOALLOC_SCRATCH_BYTES = 64 << 20
 MAX_AXIS = 256
 
@@ -30,7 +37,7 @@ def cells_per_frame(n_axis: int) -> int:
     return 4096 if n_axis <= 64 else n_axis * n_axis
 
 EXPORTS = [
-    "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version",
+    "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version", "slam_abi_revision", "slam_set_fused", "slam_get_fused",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean", "slam_pivot_mean_f64",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
@@ -96,6 +103,11 @@ def load() -> C.CDLL:
         lib.slam_last_error.argtypes = [vp]
         lib.slam_last_error.restype = C.c_char_p
         lib.slam_version.restype = C.c_char_p
+        if not hasattr(lib, "slam_abi_revision") or lib.slam_abi_revision() != ABI_REVISION:
+            raise RuntimeError(f"{LIB_PATH}: the library's binary interface is not revision {ABI_REVISION}, the one this "
+                               "binding was written against -- rebuild the library or update the binding")
+        lib.slam_set_fused.argtypes = [vp, C.c_int]
+        lib.slam_get_fused.argtypes = [vp]
         lib.slam_hex_unpack.argtypes = [vp, vp, sz, vp, sz, psz]
         lib.slam_parse_records.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
         lib.slam_parse_text.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, psz, psz]
@@ -164,6 +176,13 @@ class Context:
 
     def sync(self) -> None:
         self.check(self.lib.slam_sync(self.h))
+
+    def set_fused(self, on: bool) -> None:
+        """Batched calls that decode and correct: one fused kernel (True) or two (False); see slam_set_fused."""
+        self.check(self.lib.slam_set_fused(self.h, 1 if on else 0))
+
+    def get_fused(self) -> bool:
+        return bool(self.check(self.lib.slam_get_fused(self.h)))
 
     def close(self) -> None:
         if getattr(self, "h", None):

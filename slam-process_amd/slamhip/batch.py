@@ -7,6 +7,9 @@ frames.  `process_files_sharded` does the same for the files one rank owns and g
 """
 from __future__ import annotations
 
+import os
+import threading
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -17,18 +20,35 @@ from .pipeline import FramePipeline, STAGE_ALL
 
 
 # Buffers and pipelines of the default configuration are kept between calls (a pipeline owns a few hundred MB of device
-# arrays and a library workspace: building one per call costs more than processing nineteen captures).
-_CACHE: Dict[tuple, object] = {}
+# arrays and a library workspace: building one per call costs more than processing nineteen captures).  Entries are
+# keyed by the calling thread as well, so two threads never share a staging buffer or a pipeline; the least recently
+# used entry goes first; clear_cache() releases everything.  process_texts itself is re-entrant across threads, not
+# within one (a call reuses its thread's buffers).
+_CACHE: "OrderedDict[tuple, object]" = OrderedDict()
 _CACHE_MAX = 6
+_CACHE_LOCK = threading.Lock()
 
 
 def _cached(key, make):
-    v = _CACHE.get(key)
-    if v is None:
+    key = (threading.get_ident(), os.environ.get("SLAMHIP_FUSED", "")) + tuple(key)
+    with _CACHE_LOCK:
+        v = _CACHE.get(key)
+        if v is not None:
+            _CACHE.move_to_end(key)
+            return v
         while len(_CACHE) >= _CACHE_MAX:
-            _CACHE.pop(next(iter(_CACHE)))
-        v = _CACHE[key] = make()
+            _CACHE.popitem(last=False)
+    v = make()
+    with _CACHE_LOCK:
+        _CACHE[key] = v
     return v
+
+
+def clear_cache() -> None:
+    """Drop the staging buffers and pipelines kept between calls (their device memory goes back to torch's allocator
+    and the pipelines' library workspaces are freed)."""
+    with _CACHE_LOCK:
+        _CACHE.clear()
 
 
 def _pack(chunks: Sequence[np.ndarray], device) -> tuple:

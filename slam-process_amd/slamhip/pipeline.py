@@ -43,13 +43,15 @@ class FramePipeline:
                  vmax: Optional[float] = None, cycle: int = ops.CYCLE, tol: int = ops.TOL,
                  mod_base: int = ops.MOD_BASE, src_is_bytes: bool = False, n_tile_slots: Optional[int] = None,
                  n_compact_slots: int = 1, reserve: bool = True, upscale: int = 1,
-                 full_grid: Optional[bool] = None):
+                 full_grid: Optional[bool] = None, fused: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("FramePipeline needs a GPU (the HIP path has no CPU fallback)")
         self.dev = torch.device("cuda", device)
         # A ctx of its own: the library workspace this pipeline reserves is never re-pointed by other callers of the
         # process-wide ctx (ops.*, other pipelines), so graphs captured from run() stay valid as long as it lives.
         self.ctx = _lib.Context(device)
+        if fused is not None:             # None: the library's default (or the environment's SLAMHIP_FUSED)
+            self.ctx.set_fused(bool(fused))
         self.F = int(max_frames)
         self.max_text_len = int(max_text_len)
         self.row_tiles = int(self.ctx.lib.slam_row_tiles(self.max_text_len, 1 if src_is_bytes else 0))
@@ -192,7 +194,7 @@ class FramePipeline:
     def frame_kept(self, f: int, st: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
         """Corrected rows of frame f in order (the used entries of its blocks, concatenated)."""
         st = self.stats_host() if st is None else st
-        rc, KB, S = self.row_cap, self.kept_blocks, _lib.KEPT_BLOCK
+        rc, KB, S = self.row_cap, self.kept_blocks, _lib.kept_unit(st[f, _lib.STAT_LAYOUT])
         span = int(st[f, _lib.STAT_ROW_SLOTS])
         nb = (span + S - 1) // S
         cnt = self.kept_cnt[f * KB:f * KB + nb].to(torch.int64)

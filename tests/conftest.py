@@ -19,6 +19,23 @@ def pytest_configure(config):
     config.addinivalue_line("filterwarnings", "ignore:Glyph .* missing from font:UserWarning")
 
 
+def pytest_generate_tests(metafunc):
+    """Every GPU test runs twice: with the fused decode + correct kernel (the batched calls' default) and with the two
+    separate kernels.  Contexts read SLAMHIP_FUSED when they are created, so the pipelines a test builds follow it."""
+    if metafunc.definition.get_closest_marker("gpu") is not None:
+        metafunc.fixturenames.append("_kernel_mode")
+        metafunc.parametrize("_kernel_mode", ["fused", "split"], indirect=True)
+
+
+@pytest.fixture
+def _kernel_mode(request, monkeypatch):
+    monkeypatch.setenv("SLAMHIP_FUSED", "1" if request.param == "fused" else "0")
+    from slamhip import batch
+    batch.clear_cache()
+    yield request.param
+    batch.clear_cache()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

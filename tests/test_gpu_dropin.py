@@ -471,7 +471,7 @@ def test_batch_beyond_4_gib_arrays_matches_small_batches():
     big.set_uniform_layout(F, stride, tl)
     big.run(text)
     st = big.stats_host()
-    assert int(st[:, 1].sum()) == 0 and int(st[:, 15].sum()) == 0          # strict text, single pass everywhere
+    assert int(st[:, 1].sum()) == 0 and int((st[:, 15] & 1).sum()) == 0    # strict text, single pass everywhere
     assert big.row_cap * F * 4 > 2 ** 32
     pick = [0, 1, 549, 550, 1098, 1099]
     small = FramePipeline(len(pick), tl, tile_w=256, tile_h=256, mapping=mapping, lut=lut)
@@ -609,7 +609,7 @@ def test_plain_c_host_of_the_batched_entry_points():
         G.build()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "batch ok" in r.stdout, (r.stdout, r.stderr)
-    assert "frame_onepass" in r.stdout and "rows_finish" in r.stdout            # its own timer table names the kernels
+    assert ("frame_onepass" in r.stdout or "frame_fused" in r.stdout) and "rows_finish" in r.stdout   # its own timer table names the kernels
 
 
 def test_complete_capture_end_to_end():
