@@ -397,9 +397,11 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
     if kern:
         table, roof, ach = kernel_accounting(kern, nbytes, valid, kept, tile_bytes, lambda launches: F * K / max(launches, 1),
                                              B, N, upscale)
-    served = int(((st[:, _lib.STAT_LAYOUT] & _lib.LAYOUT_KEPT_GROUPS) != 0).sum())
+    served = int(((st[:, _lib.STAT_LAYOUT] & _lib.LAYOUT_KEPT_TILES) != 0).sum())
+    why = st[:, _lib.STAT_LAYOUT] >> _lib.LAYOUT_FUSED_WHY_SHIFT              # frames the fused kernel handed on, by reason bits
+    why = {int(w): int((why == w).sum()) for w in np.unique(why) if w}
     res = dict(value=fps_rank * world, ms_per_step=dt / K * 1e3, F=F, n_distinct=n_distinct, tl=tl, kappa=kappa,
-               fused=pipe.ctx.get_fused(), fused_frames=served,
+               fused=pipe.ctx.get_fused(), fused_frames=served, fused_gave_up=why,
                alg_frame=alg_frame, fps_rank=fps_rank, kernels=table, roofline=roof, achieved=ach,
                gather_verified=verified, gather_rates=gather_rates if world > 1 else None)
     return res, pipe, text
@@ -494,7 +496,8 @@ def main():
                                f"tile {a.tile}x{a.tile} RGBA" + (f", beam table up-scaled x{a.upscale}" if a.upscale > 1 else ""),
                    "frames_per_step": F, "beams": B, "samples": N,
                    "decode_correct": ("one fused kernel" if res["fused"] else "separate kernels") +
-                                     (f" ({res['fused_frames']} of {F} frames of the last batch served by it)" if res["fused"] else ""),
+                                     (f" ({res['fused_frames']} of {F} frames of the last batch served by it" +
+                                      (f"; handed on, by reason bits: {res['fused_gave_up']}" if res["fused_gave_up"] else "") + ")" if res["fused"] else ""),
                    "parallelism": f"frames sharded over {world} GPU(s)" +
                                   {"none": "", "tiles": ", 4 MiB tiles gathered to rank 0 every step (RCCL)",
                                    "compact": ", tiles gathered to rank 0 every step in compact form (cell colours + "

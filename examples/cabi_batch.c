@@ -114,7 +114,7 @@ int main(void)
 
     const uint32_t T = slam_row_tiles((uint32_t)tl, 0);
     const uint32_t row_cap = (T * SLAM_TILE_SLOTS + 15u) & ~15u;
-    const uint32_t KB = (row_cap + SLAM_KEPT_BLOCK - 1) / SLAM_KEPT_BLOCK;
+    const uint32_t KB = slam_kept_blocks(row_cap, (uint32_t)tl, 0);
     outputs a, b;
     alloc_outputs(&a, row_cap, T, KB);
     alloc_outputs(&b, row_cap, T, KB);
@@ -150,7 +150,7 @@ int main(void)
         CHECK(s[SLAM_STAT_ALLNAN] == 0 && s[SLAM_STAT_N_AOD] > 0 && s[SLAM_STAT_N_AOA] == NA);
         uint32_t rows = 0, kept = 0;
         for (uint32_t t = 0; t < T; t++) rows += tc[f * T + t];
-        const uint32_t ku = (s[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
+        const uint32_t ku = (s[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_TILES) ? SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
         for (uint32_t k = 0; k < (s[SLAM_STAT_ROW_SLOTS] + ku - 1) / ku; k++) kept += kc[f * KB + k];   /* the frame's blocks */
         CHECK(rows == s[SLAM_STAT_VALID] && kept == s[SLAM_STAT_KEPT]);       /* the slots' counts add up to the counters */
         size_t opaque = 0, clear = 0;                   /* a cell with no finite value within the blur's reach stays transparent */
@@ -194,8 +194,8 @@ int main(void)
         uint32_t *d_kck = to_host(a.kclk, (size_t)row_cap * 4);
         i = 0;
         same = 1;
-        /* blocks of the corrected-row arrays: SLAM_KEPT_BLOCK entries, or 16 tiles' entries where the fused kernel served the frame */
-        const uint32_t unit = (st[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
+        /* blocks of the corrected-row arrays: SLAM_KEPT_BLOCK entries, or one tile's entries where the fused kernel served the frame */
+        const uint32_t unit = (st[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_TILES) ? SLAM_TILE_SLOTS : SLAM_KEPT_BLOCK;
         for (uint32_t blk = 0; blk < KB && (size_t)blk * unit < row_cap; blk++)
             for (uint32_t k = 0; k < kc[blk]; k++, i++) {
                 const size_t e = (size_t)blk * unit + k;

@@ -53,7 +53,7 @@ const char *slam_last_error(slam_ctx *ctx);
 const char *slam_version(void);
 /* Revision of this binary interface (struct layouts, argument lists, buffer layouts): a binding compares it with
  * the SLAM_ABI_REVISION it was written against before the first call. */
-#define SLAM_ABI_REVISION 3
+#define SLAM_ABI_REVISION 4
 int slam_abi_revision(void);
 
 /* ---- a1: hex text -> bytes ---------------------------------------------------------------
@@ -191,10 +191,10 @@ typedef struct slam_batch {
      * src_is_bytes); the other entries of a tile are unused.  Concatenating the tiles' used entries gives
      * the reference's record list.  Corrected rows (kept_*) use the same scheme over blocks of U entries:
      * the rows kept among entries [b*U, (b+1)*U) of the decoded arrays sit, in order, at the front of the same
-     * entries of the kept arrays, kept_cnt_dev[f*KB + b] of them, KB = ceil(row_cap / SLAM_KEPT_BLOCK).  U is a
-     * property of the frame: SLAM_KEPT_BLOCK, or SLAM_KEPT_GROUP_TILES * SLAM_TILE_SLOTS when bit
-     * SLAM_LAYOUT_KEPT_GROUPS of the frame's SLAM_STAT_LAYOUT word is set (frames the fused decode + correct
-     * kernel served, see slam_set_fused). */
+     * entries of the kept arrays, kept_cnt_dev[f*KB + b] of them, KB = slam_kept_blocks(row_cap, max_text_len,
+     * src_is_bytes).  U is a property of the frame: SLAM_KEPT_BLOCK, or SLAM_TILE_SLOTS (a block per tile, like
+     * the decoded records) when bit SLAM_LAYOUT_KEPT_TILES of the frame's SLAM_STAT_LAYOUT word is set (frames
+     * the fused decode + correct kernel served, see slam_set_fused). */
     uint32_t row_cap;             /* multiple of 16, >= T * SLAM_TILE_SLOTS                       */
     uint8_t *flag_dev, *ue_dev, *bs_dev;        /* decoded records                               */
     uint32_t *rss_dev, *clk_dev;
@@ -224,10 +224,11 @@ size_t slam_batch_sizeof(void);
 
 #define SLAM_TILE_BYTES    3024   /* data bytes per decoded-record tile                           */
 #define SLAM_TILE_SLOTS     276   /* entries reserved per tile in the decoded-record arrays        */
-#define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays ...            */
-#define SLAM_KEPT_GROUP_TILES 16  /* ... or this many tiles' entries per block (SLAM_LAYOUT_KEPT_GROUPS) */
+#define SLAM_KEPT_BLOCK    1024   /* entries per block of the corrected-row arrays (or SLAM_TILE_SLOTS: SLAM_LAYOUT_KEPT_TILES) */
 /* Tiles per frame for frames of up to max_text_len text bytes (or data bytes when src_is_bytes). */
 uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
+/* Counts per frame in kept_cnt_dev: enough for either block size, max(ceil(row_cap / SLAM_KEPT_BLOCK), slam_row_tiles(...)). */
+uint32_t slam_kept_blocks(uint32_t row_cap, uint32_t max_text_len, uint32_t src_is_bytes);
 
 #define SLAM_STAT_WORDS      16
 #define SLAM_STAT_NBYTES      0   /* data bytes decoded from the text                            */
@@ -248,7 +249,17 @@ uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes);
 #define SLAM_STAT_ROW_SLOTS  14   /* entries of the decoded-record arrays this frame spans         */
 #define SLAM_STAT_LAYOUT     15   /* bits: how the frame's row arrays are laid out                  */
 #define SLAM_LAYOUT_TWO_PASS     1u  /* decoded by the two-pass kernels: entries are dense (all tiles full but the last) */
-#define SLAM_LAYOUT_KEPT_GROUPS  2u  /* corrected rows are slotted per SLAM_KEPT_GROUP_TILES tiles, not per SLAM_KEPT_BLOCK */
+#define SLAM_LAYOUT_KEPT_TILES   2u  /* corrected rows are slotted per tile (SLAM_TILE_SLOTS entries), not per SLAM_KEPT_BLOCK */
+/* Diagnostic, bits 8 and up: why the fused decode + correct kernel handed the frame to the separate kernels (0: it
+ * did not).  SLAM_FUSED_GAVE_UP_* << SLAM_LAYOUT_FUSED_WHY_SHIFT, several may be set. */
+#define SLAM_LAYOUT_FUSED_WHY_SHIFT 8
+#define SLAM_FUSED_GAVE_UP_TILE_LISTS   1u  /* more than 16 baselines or 8 sweep starts within one tile               */
+#define SLAM_FUSED_GAVE_UP_UNSYNC       2u  /* a look-behind run does not pin the scan position (two-pass frame)       */
+#define SLAM_FUSED_GAVE_UP_FIRST_ROW    4u  /* the record before a workgroup's first row was not at hand               */
+#define SLAM_FUSED_GAVE_UP_WG_LISTS     8u  /* more than 7 sweep starts in 16 tiles, or a border sweep's list too long */
+#define SLAM_FUSED_GAVE_UP_TIMEOUT     16u  /* a neighbouring workgroup's baselines did not arrive in time             */
+#define SLAM_FUSED_GAVE_UP_NEIGHBOUR   32u  /* a neighbour gave up, or a sweep spans more workgroups than are walked   */
+#define SLAM_FUSED_GAVE_UP_GROUP_SIZE  64u  /* a sweep of more than 256 baselines                                      */
 
 /* Replaces, per frame, the chain main() -> _read_bytes -> _parse_groups
  * (serial_hex_to_excel_v3.py:153-154), process_excel_filtered's data path

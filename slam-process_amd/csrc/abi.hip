@@ -65,7 +65,7 @@ extern "C" int slam_abi_revision(void) { return SLAM_ABI_REVISION; }
 
 // the library's default for slam_set_fused, unless the environment says otherwise
 #ifndef SLAM_FUSED_DEFAULT
-#define SLAM_FUSED_DEFAULT 1
+#define SLAM_FUSED_DEFAULT 0
 #endif
 
 extern "C" int slam_ctx_create(int device, slam_ctx **out)
@@ -807,7 +807,7 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {
-    size_t fw[6], cw[16], rw[12], tc, tb[3], zw[5];
+    size_t fw[6], cw[16], rw[12], tc, kc, tb[3], zw[5];
     uint32_t nt_max, st_max, bl_cap;
     int32_t n_axis;             // the batch's, or 64 where the batch leaves it unset (no render stage)
     size_t total;
@@ -829,6 +829,7 @@ static int plan_batch(slam_ctx *ctx, const slam_batch *bt, batch_plan &bp)
                          "slam_batch: row_cap must be a multiple of 16 and >= slam_row_tiles(...) * SLAM_TILE_SLOTS");
     ws_plan p;
     bp.tc = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
+    bp.kc = p.add((size_t)bt->n_frames * std::max((bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, bp.st_max) * sizeof(uint32_t));
     bp.tb[0] = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
     bp.tb[1] = p.add((size_t)bt->n_frames * bp.st_max * sizeof(uint32_t));
     bp.tb[2] = p.add((size_t)bt->n_frames * bp.st_max * BL_PAY_CAP * sizeof(unsigned long long));
@@ -913,8 +914,8 @@ static int run_batch(slam_ctx *ctx, const slam_batch *bt, uint32_t stages, const
     tbits.pay = (unsigned long long *)(b + bp.tb[2]);
     tbits.stride = bp.st_max;
     if (stages & 2u) rows.bits = tbits;          // the framing pass leaves the correction's per-tile bits
-    const uint32_t kept_stride = (bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : cws.rt_nkept;
+    const uint32_t kept_stride = std::max((bt->row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, bp.st_max);
+    uint32_t *kept_cnt = bt->kept_cnt_dev ? bt->kept_cnt_dev : (uint32_t *)(b + bp.kc);
     correct_params prm;
     if (stages & 2u) {
         prm.set_cycle(bt->cycle);

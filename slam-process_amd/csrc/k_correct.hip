@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t *a, uint32_t *b, ui
         }
         if (grp_row) {
             // the kernels that follow slot the kept rows per ROWS_PER_BLOCK entries, whatever an earlier call left
-            stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] &= ~SLAM_LAYOUT_KEPT_GROUPS;
+            stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] &= ~SLAM_LAYOUT_KEPT_TILES;
             stats[f * SLAM_STAT_WORDS + SLAM_STAT_KEPT] = 0;       // accumulated by the fused correction kernel
             grp_row[(size_t)f * grp_stride + ca] = n;
             grp_bl[(size_t)f * grp_stride + ca] = nbl;
@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(256) void k_kept_total(uint32_t F, const uint32_t *
     if (f >= F) return;
     const uint32_t n = stats[f * SLAM_STAT_WORDS + SLAM_STAT_ROW_SLOTS];
     // blocks of ROWS_PER_BLOCK entries, or of a fused workgroup's entries where the fused kernel served the frame
-    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? (uint32_t)FUSED_ENTRIES : (uint32_t)ROWS_PER_BLOCK;
+    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_TILES) ? (uint32_t)SLOT_ROWS : (uint32_t)ROWS_PER_BLOCK;
     const uint32_t nblk = (n + unit - 1) / unit;
     uint32_t k = 0;
     for (uint32_t b = lane; b < nblk; b += 64) k += kept_cnt[(size_t)f * kept_stride + b];

@@ -589,6 +589,11 @@ extern "C" uint32_t slam_row_tiles(uint32_t max_text_len, uint32_t src_is_bytes)
     return slot_tiles_for(src_is_bytes ? SRC_RAW : SRC_TEXT3, max_text_len);
 }
 
+extern "C" uint32_t slam_kept_blocks(uint32_t row_cap, uint32_t max_text_len, uint32_t src_is_bytes)
+{
+    return std::max((row_cap + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, slam_row_tiles(max_text_len, src_is_bytes));
+}
+
 void frame_ws::plan(ws_plan &p, uint32_t F, uint32_t nt_max, size_t off[6])
 {
     off[4] = p.add((size_t)F * sizeof(frame_desc));

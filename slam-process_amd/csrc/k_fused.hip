@@ -12,26 +12,35 @@
 //
 // A sweep (group) does not end where a workgroup ends, so workgroups exchange baselines: after phase A each one
 // publishes the baselines of its two border sweeps -- those before its first group start and those after its last --
-// with write-through stores, raises a flag, and reads what its neighbours published (backwards until a workgroup with
-// a group start, forwards likewise).  A workgroup only ever waits for workgroups that publish without waiting for
-// anybody, so whatever order the hardware dispatches them in, some workgroup can always finish; waits are bounded by
-// a clock all the same, and a wait that runs out gives the frame up like every other case the kernel does not serve:
-// the frame is flagged and the separate correction kernels redo it from the row arrays (which are complete).
+// with write-through stores and then a header word (how many of each, how many group starts), and reads what its
+// neighbours published (backwards until a workgroup with a group start, forwards likewise).  A workgroup only ever
+// waits for workgroups that publish without waiting for anybody, so whatever order the hardware dispatches them in,
+// some workgroup can always finish; waits are bounded by a clock all the same, and a wait that runs out gives the
+// frame up like every other case the kernel does not serve: the frame is flagged and the separate correction
+// kernels redo it from the row arrays (which are complete).
 //
-// Per group a workgroup touches (the one running into it, those starting in it): the baselines in row order
-// (neighbours' before / own / neighbours' after) are sorted by one wave into a table of distinct phases
-// (clk_b mod CYCLE, earliest baseline of each phase) in LDS; every FLAG = 0 row does a lower-bound search there and
-// takes the nearer of the two circular neighbours (ties: the earlier baseline), as k_rows_finish does.  Kept rows are
-// packed in place, tile by tile, then gathered into the front of the workgroup's own block of the kept arrays.
+// Phase B in steps, three block barriers in all: (1) wave 0 gathers the tiles' lists into the workgroup's and publishes
+// while waves 1 and 2 poll the neighbours behind and ahead; (2) per group a workgroup touches (the one running into
+// it, those starting in it) one wave sorts the baselines in row order (neighbours' before / own / neighbours' after)
+// into a table of distinct phases (clk_b mod CYCLE, earliest baseline of each phase) in LDS; (3) every wave takes
+// its two tiles: every FLAG = 0 row does a lower-bound search in its group's table and takes the nearer of the two
+// circular neighbours (ties: the earlier baseline), as k_rows_finish does -- five 64-row chunks of a tile side by
+// side, so the dependent LDS reads of one search overlap with the others' -- packs the kept rows in place and writes
+// them to the front of the tile's own entries of the kept arrays (SLAM_LAYOUT_KEPT_TILES).
 //
 // Served: 0 <= 2*TOL < CYCLE < 2^24, MOD_BASE a power of two (host-side switch, fused_supported); per frame: every
 // group of at most 256 baselines, at most 7 group starts per workgroup, at most 16 baselines and 8 group starts per
-// tile, a border sweep within 12 workgroups either side.  Everything else: flagged, redone.
+// tile, a border sweep within 12 workgroups either side.  Everything else: flagged (SLAM_FUSED_GAVE_UP_* says why), redone.
 
 #include "pipeline.hpp"
 
 #include "correct_device.hpp"
 #include "frame_device.hpp"
+
+// tuning builds (SLAM_EXTRA_FLAGS=-DFU_EXP=n): leave out parts of phase B to see what each costs; results are wrong then
+#ifndef FU_EXP
+#define FU_EXP 0
+#endif
 
 namespace {
 
@@ -42,15 +51,23 @@ constexpr int FU_GST = 8;                            // group starts listed per 
 constexpr int FU_MAXG = 8;                           // groups a workgroup corrects: the one running into it + 7 starting in it
 constexpr int FU_NBR = 256;                          // baselines taken from the neighbours, per side
 constexpr int FU_MAXM = 256;                         // baselines per group
-constexpr int FU_POOL = 1024;                        // table entries (padded) of all the workgroup's groups together
+constexpr int FU_POOL = 1024;                        // table entries of all the workgroup's groups together (each padded alike)
 constexpr int FU_HOPS = 12;                          // workgroups walked per side
 constexpr uint64_t FU_TIMEOUT = 1000000ull;          // ticks of the 100 MHz wall clock a wait may last (10 ms)
 constexpr int FU_WBL = FUSED_TILES * FU_BLT;         // 256 own baselines at most
-static_assert(FU_TPW * FU_WAVES == FUSED_TILES && FU_MAXG <= FU_WAVES, "one wave sorts one group");
-static_assert(1 + 2 * 127 <= FUSED_PUB_WORDS, "published lists fit their words");
+constexpr int FU_CHUNKS = (SLOT_ROWS + 63) / 64;     // 64-row chunks of a tile
 constexpr uint32_t FU_PUB_LIST = 127;                // baselines per published list
+static_assert(FU_TPW * FU_WAVES == FUSED_TILES && FU_MAXG <= FU_WAVES, "one wave sorts one group");
+static_assert(2 * FU_PUB_LIST <= FUSED_PUB_WORDS, "published lists fit their words");
+static_assert(FUSED_TILES <= 64 && FU_HOPS < 64, "one lane per tile / per hop");
 
-// header word a workgroup publishes: group starts | baselines before the first << 16 | after the last << 32 | gave up << 48
+// Header word a workgroup publishes (also the "published" signal: the words are zeroed before every launch):
+// bit 31 set | gave up << 30 | baselines after the last group start << 16 | before the first << 8 | group starts
+constexpr uint32_t HDR_VALID = 0x80000000u, HDR_FAIL = 0x40000000u;
+__device__ __forceinline__ uint32_t hdr_ng(uint32_t h) { return h & 0xFFu; }
+__device__ __forceinline__ uint32_t hdr_head(uint32_t h) { return (h >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t hdr_tail(uint32_t h) { return (h >> 16) & 0xFFu; }
+
 __device__ __forceinline__ unsigned long long ld_pub(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // bypasses this CU's L1
@@ -59,22 +76,41 @@ __device__ __forceinline__ void st_pub(unsigned long long *p, unsigned long long
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // write-through
 }
-
-// Lane 0 polls the flag (relaxed, sleeping in between) until it reads 1 or the clock runs out; wave-uniform result.
-__device__ __forceinline__ bool wait_published(const uint32_t *flag, uint32_t lane)
+// the header goes out behind everything the wave stored before it
+__device__ __forceinline__ void st_hdr(uint32_t *p, uint32_t v)
 {
-    uint32_t ok = 0;
-    if (lane == 0) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 1; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > FU_TIMEOUT) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Walk over the neighbours' headers, one lane per hop (lane l looks at the workgroup l + 1 places away in direction
+// `dir`, `reach` of them exist): polls until the headers from the nearest one up to the first that closes the sweep
+// (a workgroup with a group start, one that gave up, or the last that exists) have all arrived, or the clock runs
+// out.  Returns this lane's header (0: not needed or never arrived); *hops = how many workgroups take part (0: no
+// neighbour needed), *ok = false when a header did not arrive in time.
+__device__ __forceinline__ uint32_t poll_headers(const uint32_t *flag0, int dir, uint32_t reach, uint32_t lane,
+                                                 uint32_t *hops, bool *ok)
+{
+    const uint32_t n = min(reach, (uint32_t)FU_HOPS);
+    *hops = 0;
+    *ok = true;
+    if (n == 0) return 0;
+    const uint32_t *mine = flag0 + (ptrdiff_t)dir * (ptrdiff_t)(lane + 1);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t h = 0;
+    for (;;) {
+        if (lane < n && !(h & HDR_VALID)) h = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t valid = __ballot((h & HDR_VALID) != 0);
+        const uint64_t closing = __ballot((h & HDR_VALID) && (hdr_ng(h) != 0 || (h & HDR_FAIL)));
+        const uint32_t run = (uint32_t)__builtin_ctzll(~valid);                     // headers in a row from the nearest
+        const uint32_t first = closing ? (uint32_t)__builtin_ctzll(closing) : 64u;
+        if (first < run) { *hops = first + 1; break; }
+        if (run >= n) { *hops = n; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > FU_TIMEOUT) { *ok = false; break; }
+        __builtin_amdgcn_s_sleep(8);
     }
-    ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)ok);
-    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return ok != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return lane < *hops ? h : 0u;
 }
 
 template <int MODE>
@@ -89,11 +125,11 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
     __shared__ unsigned long long t_bl[FUSED_TILES][FU_BLT];   // per tile: baselines, clk of the row before | bs << 32 | entry << 40
     __shared__ uint16_t t_gs[FUSED_TILES][FU_GST];       // per tile: entries that start a group
     __shared__ uint32_t t_cnt[FUSED_TILES], t_nbound[FUSED_TILES], t_nbase[FUSED_TILES], t_state[FUSED_TILES];
-    __shared__ uint32_t t_gbase[FUSED_TILES], t_bbase[FUSED_TILES], t_nk[FUSED_TILES];
+    __shared__ uint32_t t_gbase[FUSED_TILES], t_bbase[FUSED_TILES];
     __shared__ uint32_t g_start[FU_MAXG + 1], g_bllo[FU_MAXG + 2];
-    __shared__ uint32_t tab_off[FU_MAXG], tab_nd[FU_MAXG], tab_P[FU_MAXG];
+    __shared__ uint32_t tab_nd[FU_MAXG];
     __shared__ uint32_t wave_cnt[FU_WAVES][2];
-    __shared__ uint32_t s_fail, s_ng, s_nb, s_npred, s_nsucc, s_first_start, s_has_rows;
+    __shared__ uint32_t s_fail, s_ng, s_npred, s_nsucc;
 
     const uint32_t f = blockIdx.y, c = blockIdx.x, wv = threadIdx.x >> 6, lane = lane_id(), tid = threadIdx.x;
     uint32_t *st = stats + f * SLAM_STAT_WORDS;
@@ -104,11 +140,7 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
     if (st[SLAM_STAT_LAYOUT] & SLAM_LAYOUT_TWO_PASS) {
         // the frame goes to the two-pass kernels (asked for by the caller, or flagged by a workgroup of this launch that
         // is already done): nothing to do here, but a neighbour that started earlier may be waiting for this workgroup
-        if (tid == 0) {
-            st_pub(fw.pub + ((size_t)f * fw.wg_stride + c) * FUSED_PUB_WORDS, 1ull << 48);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(fw.flag + (size_t)f * fw.wg_stride + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) st_hdr(fw.flag + (size_t)f * fw.wg_stride + c, HDR_VALID | HDR_FAIL);
         return;
     }
     if (tid == 0) { s_fail = 0; s_npred = 0; s_nsucc = 0; }
@@ -274,7 +306,7 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                 }
                 nbase += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
             }
-            if (nbase > (uint32_t)FU_BLT || nbound > (uint32_t)FU_GST) giveup = 1;
+            if (nbase > (uint32_t)FU_BLT || nbound > (uint32_t)FU_GST) giveup = SLAM_FUSED_GAVE_UP_TILE_LISTS;
             if (lane == 0) { t_cnt[ti] = C; t_nbound[ti] = nbound; t_nbase[ti] = nbase; t_state[ti] = C ? pstate : 1u; }
         }
         accv += cnt;
@@ -284,8 +316,9 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
     accd = wave_sum(accd);
     if (lane == 0) { wave_cnt[wv][0] = accv; wave_cnt[wv][1] = accd; }
     if (bad & BAD_MASK) st[SLAM_STAT_NOT_STRICT] = 1;
-    if (unsync) { st[SLAM_STAT_LAYOUT] = SLAM_LAYOUT_TWO_PASS; giveup = 1; }
-    if (__any(giveup != 0u) && lane == 0) atomicOr(&s_fail, 1u);
+    if (unsync) { st[SLAM_STAT_LAYOUT] = SLAM_LAYOUT_TWO_PASS; giveup |= SLAM_FUSED_GAVE_UP_UNSYNC; }
+    giveup = (uint32_t)__builtin_amdgcn_readfirstlane((int)giveup);         // wave-uniform bits, and lane 0's own
+    if (giveup && lane == 0) atomicOr(&s_fail, giveup);
     __syncthreads();
 
     // ---- phase B ------------------------------------------------------------------------------------------------
@@ -294,23 +327,28 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
     unsigned long long *wbl = reinterpret_cast<unsigned long long *>(pool);                 // own baselines, row order
     unsigned long long *pred = reinterpret_cast<unsigned long long *>(pool + 2 * FU_WBL);   // neighbours' before, filled from the back
     unsigned long long *succ = pred + FU_NBR;                                               // neighbours' after
-    uint32_t *t_rb = pool + 2 * FU_WBL + 4 * FU_NBR;                                        // tables: phase ...
-    uint32_t *t_pv = t_rb + FU_POOL;                                                        // ... index in group << 8 | beam term
+    uint2 *tab = reinterpret_cast<uint2 *>(pool + 2 * FU_WBL + 4 * FU_NBR);                 // tables: (phase, index in group << 8 | beam term)
     static_assert(2 * FU_WBL + 4 * FU_NBR + 2 * FU_POOL <= FU_WAVES * FRAME_TILE_DW, "phase B fits the text tiles' LDS");
     const size_t pix = (size_t)f * fw.wg_stride + c;
     unsigned long long *mypub = fw.pub + pix * FUSED_PUB_WORDS;
 
-    if (wv == 0) {
-        // a tile whose look-behind run held no usable record: its first row's bits from the last row of the tile before
-        // (inside the workgroup; the workgroup's own first rows cannot be settled here)
+    // ---- step 1: wave 0 puts the workgroup's lists together and publishes; waves 1 and 2 fetch the neighbours' ----
+    if (wv == 0 && !(FU_EXP & 16)) {
         uint32_t fail = s_fail;
-        bool seen_rows = false;
-        for (uint32_t ti = 0; ti < (uint32_t)FUSED_TILES; ti++) {          // wave-uniform walk
-            const uint32_t C = t_cnt[ti];
-            if (!C) continue;
-            if (t_state[ti] == 0u) {
-                if (!seen_rows) { fail = 1; }
-                else if (lane == 0) {
+        const bool tl = lane < (uint32_t)FUSED_TILES;
+        const uint32_t Cl = tl ? t_cnt[lane] : 0u, stl = tl ? t_state[lane] : 1u;
+        const uint64_t rowsm = __ballot(Cl != 0u);
+        uint64_t fix = __ballot(Cl != 0u && stl == 0u);
+        if (fix) {
+            // a tile whose look-behind run held no usable record: its first row's bits from the last row of the tile
+            // before (inside the workgroup; the workgroup's own first rows cannot be settled here)
+            const uint32_t first = (uint32_t)__builtin_ctzll(rowsm);
+            if ((fix >> first) & 1u) { fail |= SLAM_FUSED_GAVE_UP_FIRST_ROW; fix &= ~(1ull << first); }
+            while (fix) {                                                   // wave-uniform walk, lane 0 works
+                const uint32_t ti = (uint32_t)__builtin_ctzll(fix);
+                fix &= fix - 1;
+                uint32_t bad_fix = 0;
+                if (lane == 0) {
                     uint32_t tp = ti;
                     do { tp--; } while (!t_cnt[tp]);
                     const uint32_t lp = t_cnt[tp] - 1;
@@ -322,7 +360,7 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                     const bool bl = !b && sq8[0] == 1 && sp8[lp] == 0 && sq[SLOT_ROWS] == sp[SLOT_ROWS + lp];
                     if (b) {
                         const uint32_t n = t_nbound[ti];
-                        if (n >= (uint32_t)FU_GST) fail = 1;
+                        if (n >= (uint32_t)FU_GST) bad_fix = 1;
                         else {
                             for (uint32_t k = n; k > 0; k--) t_gs[ti][k] = t_gs[ti][k - 1];
                             t_gs[ti][0] = 0;
@@ -332,7 +370,7 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                     }
                     if (bl) {
                         const uint32_t n = t_nbase[ti];
-                        if (n >= (uint32_t)FU_BLT) fail = 1;
+                        if (n >= (uint32_t)FU_BLT) bad_fix = 1;
                         else {
                             for (uint32_t k = n; k > 0; k--) t_bl[ti][k] = t_bl[ti][k - 1];
                             t_bl[ti][0] = (unsigned long long)sp[lp] | ((unsigned long long)sq8[2 * SLOT_ROWS] << 32);
@@ -341,27 +379,29 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                         }
                     }
                 }
-                fail = (uint32_t)__builtin_amdgcn_readfirstlane((int)fail);
+                if (__builtin_amdgcn_readfirstlane((int)bad_fix)) fail |= SLAM_FUSED_GAVE_UP_TILE_LISTS;
                 wave_lds_fence();
             }
-            seen_rows = true;
         }
         // per-tile counts -> bases, totals
-        const uint32_t nbnd = lane < (uint32_t)FUSED_TILES ? t_nbound[lane] : 0u, nbs = lane < (uint32_t)FUSED_TILES ? t_nbase[lane] : 0u;
+        const uint32_t nbnd = tl ? t_nbound[lane] : 0u, nbs = tl ? t_nbase[lane] : 0u;
         const uint32_t packed = nbnd | (nbs << 16), incp = wave_incl_scan(packed), exq = incp - packed;
-        if (lane < (uint32_t)FUSED_TILES) { t_gbase[lane] = exq & 0xFFFFu; t_bbase[lane] = exq >> 16; }
+        if (tl) { t_gbase[lane] = exq & 0xFFFFu; t_bbase[lane] = exq >> 16; }
         const uint32_t tot = (uint32_t)__shfl((int)incp, FUSED_TILES - 1, 64);
         const uint32_t NG = tot & 0xFFFFu, NB = tot >> 16;
-        if (NG > (uint32_t)FU_MAXG - 1u || NB > (uint32_t)FU_WBL) fail = 1;
+        if (NG > (uint32_t)FU_MAXG - 1u || NB > (uint32_t)FU_WBL) fail |= SLAM_FUSED_GAVE_UP_WG_LISTS;
         wave_lds_fence();
         uint32_t nb_head = 0, nb_tail = 0;
         if (!fail) {
             // own group starts and baselines, in row order, entries counted from the workgroup's first
-            if (lane < (uint32_t)FUSED_TILES) {
+            if (tl)
                 for (uint32_t k = 0; k < nbnd; k++) g_start[1 + (exq & 0xFFFFu) + k] = lane * SLOT_ROWS + t_gs[lane][k];
-                for (uint32_t k = 0; k < nbs; k++) {
-                    const unsigned long long p = t_bl[lane][k];
-                    wbl[(exq >> 16) + k] = (p & 0xFFFFFFFFFFull) | ((unsigned long long)(lane * SLOT_ROWS + (uint32_t)(p >> 40)) << 40);
+#pragma unroll
+            for (int r = 0; r < FUSED_TILES * FU_BLT / 64; r++) {
+                const uint32_t idx = lane + 64u * r, ti = idx / FU_BLT, k = idx % FU_BLT;
+                if (k < t_nbase[ti]) {
+                    const unsigned long long p = t_bl[ti][k];
+                    wbl[t_bbase[ti] + k] = (p & 0xFFFFFFFFFFull) | ((unsigned long long)(ti * SLOT_ROWS + (uint32_t)(p >> 40)) << 40);
                 }
             }
             if (lane == 0) { g_start[0] = 0; g_bllo[0] = 0; g_bllo[NG + 1] = NB; }
@@ -377,104 +417,93 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                 if (s == NG) nb_tail = NB - below;
             }
             if (NG == 0) nb_head = NB;
-            if (nb_head > FU_PUB_LIST || nb_tail > FU_PUB_LIST) fail = 1;
+            if (nb_head > FU_PUB_LIST || nb_tail > FU_PUB_LIST) fail |= SLAM_FUSED_GAVE_UP_WG_LISTS;
         }
-        // publish: lists, header, then the flag behind this wave's own drain
+        // publish: lists, then the header behind this wave's own drain
         if (!fail) {
-            for (uint32_t i = lane; i < nb_head; i += 64) st_pub(mypub + 1 + i, wbl[i] & 0xFFFFFFFFFFull);
-            for (uint32_t i = lane; i < nb_tail; i += 64) st_pub(mypub + 1 + nb_head + i, wbl[NB - nb_tail + i] & 0xFFFFFFFFFFull);
+            for (uint32_t i = lane; i < nb_head; i += 64) st_pub(mypub + i, wbl[i] & 0xFFFFFFFFFFull);
+            for (uint32_t i = lane; i < nb_tail; i += 64) st_pub(mypub + nb_head + i, wbl[NB - nb_tail + i] & 0xFFFFFFFFFFull);
         }
-        if (lane == 0)
-            st_pub(mypub, (unsigned long long)NG | ((unsigned long long)nb_head << 16) | ((unsigned long long)nb_tail << 32) |
-                              ((unsigned long long)(fail ? 1u : 0u) << 48));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            __hip_atomic_store(fw.flag + pix, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st_hdr(fw.flag + pix, fail ? (HDR_VALID | HDR_FAIL) : (HDR_VALID | NG | (nb_head << 8) | (nb_tail << 16)));
             s_ng = NG;
-            s_nb = NB;
-            if (fail) s_fail = 1;
-            // does the workgroup's first row start a group?  (then no row here belongs to an earlier sweep)
-            uint32_t fs = 1, hr = 0;
-            for (uint32_t ti = 0; ti < (uint32_t)FUSED_TILES; ti++)
-                if (t_cnt[ti]) { fs = rmaskL[ti][0] & 1u; hr = 1; break; }
-            s_first_start = fs;
-            s_has_rows = hr;
+            if (fail) atomicOr(&s_fail, fail);
+            uint32_t *wc = fw.wg_cnt + pix * FUSED_CNT_WORDS;
+            uint32_t v = 0, d = 0;
+            for (int w = 0; w < FU_WAVES; w++) { v += wave_cnt[w][0]; d += wave_cnt[w][1]; }
+            wc[0] = v; wc[1] = d; wc[2] = fail ? 0u : NG; wc[3] = fail ? 0u : NB;
+        }
+    }
+    if ((FU_EXP & 16) && tid == 0) s_ng = 0;
+    if ((wv == 1 || wv == 2) && !(FU_EXP & 8)) {
+        // does the workgroup's first row start a group?  (then no row here belongs to an earlier sweep)
+        const uint32_t Cl = lane < (uint32_t)FUSED_TILES ? t_cnt[lane] : 0u;
+        const uint64_t rowsm = __ballot(Cl != 0u);
+        const bool has_rows = rowsm != 0;
+        const bool first_start = !has_rows || (rmaskL[has_rows ? __builtin_ctzll(rowsm) : 0][0] & 1u);
+        const bool back = wv == 1;
+        if (back ? !first_start : has_rows) {
+            uint32_t hops;
+            bool ok;
+            const uint32_t reach = back ? c : nwg - 1u - c;
+            const uint32_t h = poll_headers(fw.flag + pix, back ? -1 : 1, reach, lane, &hops, &ok);
+            uint32_t fail = ok ? 0u : SLAM_FUSED_GAVE_UP_TIMEOUT;
+            if (__any((h & HDR_FAIL) != 0u)) fail |= SLAM_FUSED_GAVE_UP_NEIGHBOUR;
+            // the sweep is closed by a workgroup with a group start, or by the frame's end: not by running out of hops
+            const bool closed = __any(lane + 1 == hops && hdr_ng(h) != 0u);
+            if (!fail && !closed && hops < reach) fail |= SLAM_FUSED_GAVE_UP_NEIGHBOUR;
+            // what each workgroup on the way contributes: behind, the baselines after its last group start (all of them
+            // if it has none); ahead, those before its first
+            const uint32_t ng = hdr_ng(h), nh = hdr_head(h), ntl = hdr_tail(h);
+            const uint32_t n = lane < hops ? (back ? (ng ? ntl : nh) : nh) : 0u;
+            const uint32_t so = back && ng ? nh : 0u;
+            const uint32_t inc = wave_incl_scan(n), total = (uint32_t)__shfl((int)inc, 63, 64);
+            if (total > (uint32_t)FU_NBR) fail |= SLAM_FUSED_GAVE_UP_NEIGHBOUR;
+            if (!fail) {
+                for (uint32_t d = 0; d < hops; d++) {
+                    const uint32_t nd_ = (uint32_t)__shfl((int)n, (int)d, 64), sod = (uint32_t)__shfl((int)so, (int)d, 64);
+                    const uint32_t before = (uint32_t)__shfl((int)(inc - n), (int)d, 64);
+                    const unsigned long long *src_ = fw.pub + (back ? pix - (d + 1) : pix + (d + 1)) * FUSED_PUB_WORDS + sod;
+                    // behind: the nearest workgroup's rows come last; ahead: first
+                    unsigned long long *dst = back ? pred + (FU_NBR - before - nd_) : succ + before;
+                    for (uint32_t i = lane; i < nd_; i += 64) dst[i] = ld_pub(src_ + i);
+                }
+            }
+            if (lane == 0) {
+                if (back) s_npred = fail ? 0u : total; else s_nsucc = fail ? 0u : total;
+                if (fail) atomicOr(&s_fail, fail);
+            }
         }
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) {
-            atomicOr(fw.fail + f, 1u);
-            uint32_t *wc = fw.wg_cnt + pix * FUSED_CNT_WORDS;
-            uint32_t v = 0, d = 0;
-            for (int w = 0; w < FU_WAVES; w++) { v += wave_cnt[w][0]; d += wave_cnt[w][1]; }
-            wc[0] = v; wc[1] = d; wc[2] = 0; wc[3] = 0; wc[4] = 0;
-        }
+        if (tid == 0) atomicOr(fw.fail + f, s_fail);
         return;
     }
-    const uint32_t NG = s_ng, NB = s_nb;
+    const uint32_t NG = s_ng;
 
-    // ---- neighbours: wave 1 walks back for the sweep running into the workgroup, wave 2 forward for the one leaving it
-    if (wv == 1 && !s_first_start) {
-        uint32_t np = 0, fail = 0;
-        bool closed = false;
-        for (uint32_t d = 1; d <= (uint32_t)FU_HOPS && d <= c; d++) {
-            const size_t nix = pix - d;
-            if (!wait_published(fw.flag + nix, lane)) { fail = 1; break; }
-            const unsigned long long *np_ = fw.pub + nix * FUSED_PUB_WORDS;
-            const unsigned long long hdr = ld_pub(np_);
-            if ((hdr >> 48) & 1u) { fail = 1; break; }
-            const uint32_t ng = (uint32_t)(hdr & 0xFFFFu), nh = (uint32_t)((hdr >> 16) & 0xFFFFu), ntl = (uint32_t)((hdr >> 32) & 0xFFFFu);
-            const uint32_t n = ng ? ntl : nh, so = ng ? 1u + nh : 1u;
-            if (np + n > (uint32_t)FU_NBR) { fail = 1; break; }
-            for (uint32_t i = lane; i < n; i += 64) pred[FU_NBR - np - n + i] = ld_pub(np_ + so + i);
-            np += n;
-            if (ng) { closed = true; break; }
-        }
-        // not closed: the walk reached the frame's first workgroup (its sweep starts with the frame) or ran out of hops
-        if (!closed && !fail && c > (uint32_t)FU_HOPS) fail = 1;
-        if (lane == 0) { s_npred = np; if (fail) atomicOr(&s_fail, 1u); }
-    }
-    if (wv == 2 && s_has_rows) {
-        uint32_t ns = 0, fail = 0;
-        bool closed = false;
-        for (uint32_t d = 1; d <= (uint32_t)FU_HOPS && c + d < nwg; d++) {
-            const size_t nix = pix + d;
-            if (!wait_published(fw.flag + nix, lane)) { fail = 1; break; }
-            const unsigned long long *np_ = fw.pub + nix * FUSED_PUB_WORDS;
-            const unsigned long long hdr = ld_pub(np_);
-            if ((hdr >> 48) & 1u) { fail = 1; break; }
-            const uint32_t ng = (uint32_t)(hdr & 0xFFFFu), nh = (uint32_t)((hdr >> 16) & 0xFFFFu);
-            if (ns + nh > (uint32_t)FU_NBR) { fail = 1; break; }
-            for (uint32_t i = lane; i < nh; i += 64) succ[ns + i] = ld_pub(np_ + 1 + i);
-            ns += nh;
-            if (ng) { closed = true; break; }
-        }
-        if (!closed && !fail && c + (uint32_t)FU_HOPS + 1u < nwg) fail = 1;
-        if (lane == 0) { s_nsucc = ns; if (fail) atomicOr(&s_fail, 1u); }
-    }
-    __syncthreads();
-
-    // ---- per group: baselines in row order -> table of distinct phases (one wave per group) --------------------
+    // ---- step 2: per group, baselines in row order -> table of distinct phases (one wave per group) -------------
+    // every table is padded to the same power of two above the largest group, so the search runs the same number of
+    // steps whatever group a row belongs to
+    uint32_t Pmax = 8;
     {
         const uint32_t S = NG + 1;                             // slot 0: the sweep running into the workgroup
         const uint32_t npred = s_npred, nsucc = s_nsucc;
-        uint32_t my_m = 0, my_off = 0, my_P = 0, total = 0, too_many = 0;
+        uint32_t my_m = 0, mmax = 0;
         for (uint32_t s = 0; s < S; s++) {
             uint32_t m = g_bllo[s + 1] - g_bllo[s];
             if (s == 0) m += npred;
             if (s == NG) m += nsucc;
-            if (s == 0 && s_first_start) m = 0;                // no row of the workgroup belongs to an earlier sweep
-            if (m > (uint32_t)FU_MAXM) too_many = 1;
-            uint32_t P = 8;
-            while (P <= m) P <<= 1;
-            if (!m) P = 0;
-            if (s == wv) { my_m = m; my_off = total; my_P = P; }
-            total += P;
+            if (s == wv) my_m = m;
+            mmax = max(mmax, m);
         }
-        if ((too_many || total > (uint32_t)FU_POOL) && tid == 0) atomicOr(&s_fail, 1u);
-        if (wv < S && !too_many && total <= (uint32_t)FU_POOL) {
-            const uint32_t s = wv, m = my_m;
+        while (Pmax <= mmax && Pmax <= (uint32_t)FU_POOL) Pmax <<= 1;       // bounded whatever the list words hold
+        if (mmax > (uint32_t)FU_MAXM || S * Pmax > (uint32_t)FU_POOL) {
+            if (tid == 0) atomicOr(fw.fail + f, SLAM_FUSED_GAVE_UP_GROUP_SIZE);
+            return;
+        }
+        if (wv < S && !(FU_EXP & 4)) {
+            const uint32_t s = wv, m = my_m, my_off = s * Pmax;
             uint32_t nd = 0;
             if (m) {
                 const uint32_t lo = g_bllo[s], own = g_bllo[s + 1] - lo, np = s == 0 ? npred : 0u;
@@ -514,127 +543,100 @@ void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> ko
                         const unsigned long long p = elem(idx);
                         uint32_t q, r;
                         phase_of((int32_t)(uint32_t)p, prm, &q, &r);
-                        t_rb[my_off + o] = r;
-                        t_pv[my_off + o] = (idx << 8) | (((uint32_t)(p >> 32) - q) & (uint32_t)(prm.mod_base - 1));
+                        tab[my_off + o] = make_uint2(r, (idx << 8) | (((uint32_t)(p >> 32) - q) & (uint32_t)(prm.mod_base - 1)));
                     }
                     run += (uint32_t)__popcll(km);
                 }
                 nd = run;
-                for (uint32_t i = nd + lane; i < my_P; i += 64) t_rb[my_off + i] = 0xFFFFFFFFu;
             }
-            if (lane == 0) { tab_off[s] = my_off; tab_nd[s] = nd; tab_P[s] = my_P; }
+            for (uint32_t i = nd + lane; i < Pmax; i += 64) tab[my_off + i] = make_uint2(0xFFFFFFFFu, 0u);
+            if (lane == 0) tab_nd[s] = nd;
         }
     }
     __syncthreads();
-    if (s_fail) {
-        if (tid == 0) {
-            atomicOr(fw.fail + f, 1u);
-            uint32_t *wc = fw.wg_cnt + pix * FUSED_CNT_WORDS;
-            uint32_t v = 0, d = 0;
-            for (int w = 0; w < FU_WAVES; w++) { v += wave_cnt[w][0]; d += wave_cnt[w][1]; }
-            wc[0] = v; wc[1] = d; wc[2] = 0; wc[3] = 0; wc[4] = 0;
-        }
-        return;
-    }
 
-    // ---- every wave: its two tiles' rows against their groups' tables; kept rows packed in place -----------------
-    {
+    // ---- step 3: every wave, its two tiles' rows against their groups' tables; kept rows packed in place and written
+    // to the front of the tile's own entries of the kept arrays ------------------------------------------------------
+    if (!(FU_EXP & 2)) {
         const uint32_t cyc = (uint32_t)prm.cycle, tol = (uint32_t)prm.tol, modm = (uint32_t)(prm.mod_base - 1);
         for (uint32_t j = 0; j < (uint32_t)FU_TPW; j++) {
-            const uint32_t ti = wv * FU_TPW + j;
-            const uint32_t C = t_cnt[ti];
+            const uint32_t ti = wv * FU_TPW + j, t = c * FUSED_TILES + ti;
+            if (t >= nt) break;
+            const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_cnt[ti]);
             uint32_t *stg = stage[ti];
             uint8_t *stg8 = reinterpret_cast<uint8_t *>(stg + 2 * SLOT_ROWS);
-            const uint32_t gbase = t_gbase[ti], nbnd = t_nbound[ti];
-            uint32_t k = 0;
-            for (uint32_t e0 = 0; e0 < C; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                const bool live = e < C;
-                uint32_t clk = 0, rss = 0, uev = 0;
-                bool cand = false;
+            const uint32_t gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_gbase[ti]);
+            const uint32_t nbnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_nbound[ti]);
+            uint32_t clk[FU_CHUNKS], rss[FU_CHUNKS], uev[FU_CHUNKS], tb[FU_CHUNKS], ndv[FU_CHUNKS], r1[FU_CHUNKS], q1[FU_CHUNKS], lo[FU_CHUNKS];
+            bool cand[FU_CHUNKS];
+#pragma unroll
+            for (int k = 0; k < FU_CHUNKS; k++) {
+                const uint32_t e = lane + 64u * k, ec = min(e, (uint32_t)SLOT_ROWS - 1u);
+                clk[k] = stg[ec];
+                rss[k] = stg[SLOT_ROWS + ec];
+                uev[k] = stg8[SLOT_ROWS + ec];
+                cand[k] = e < C && !((rmaskL[ti][ec >> 2] >> (12u + (ec & 3u))) & 1u);
                 uint32_t s = gbase;
-                if (live) {
-                    clk = stg[e];
-                    rss = stg[SLOT_ROWS + e];
-                    uev = stg8[SLOT_ROWS + e];
-                    cand = !((rmaskL[ti][e >> 2] >> (12u + (e & 3u))) & 1u);
-                    for (uint32_t q = 0; q < nbnd; q++) s += (t_gs[ti][q] <= e) ? 1u : 0u;
-                }
-                bool keep = false;
-                uint32_t res = 0;
-                if (cand && tab_nd[s]) {
-                    const uint32_t nd = tab_nd[s], P = tab_P[s];
-                    const uint32_t *rb = t_rb + tab_off[s], *pvv = t_pv + tab_off[s];
-                    uint32_t q1, r1;
-                    phase_of((int32_t)clk, prm, &q1, &r1);
-                    uint32_t lo = 0;
-                    for (uint32_t h = P >> 1; h; h >>= 1) lo += rb[lo + h - 1] < r1 ? h : 0u;
-                    const bool wrap_s = lo >= nd, wrap_p = lo == 0;
-                    const uint32_t is = wrap_s ? 0u : lo, ip = wrap_p ? nd - 1u : lo - 1u;
-                    const uint32_t rs_ = rb[is] + (wrap_s ? cyc : 0u) - r1, rp_ = r1 + (wrap_p ? cyc : 0u) - rb[ip];
-                    const uint32_t ps = pvv[is], pp = pvv[ip];
-                    const bool pd = rp_ < rs_ || (rp_ == rs_ && (pp >> 8) < (ps >> 8));       // ties: the earlier baseline
-                    if ((pd ? rp_ : rs_) <= tol) {
-                        const uint32_t adj = pd ? (wrap_p ? 0xFFFFFFFFu : 0u) : (wrap_s ? 1u : 0u);
-                        res = (((pd ? pp : ps) & 0xFFu) + q1 + adj) & modm;
-                        keep = true;
-                    }
-                }
-                const uint64_t km = __ballot(keep);
-                if (keep) {
-                    const uint32_t o = k + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                    stg[o] = clk;
-                    stg[SLOT_ROWS + o] = rss;
-                    stg8[SLOT_ROWS + o] = (uint8_t)uev;
-                    stg8[2 * SLOT_ROWS + o] = (uint8_t)res;
-                }
-                k += (uint32_t)__popcll(km);
-                wave_lds_fence();
+                for (uint32_t q = 0; q < nbnd; q++) s += (t_gs[ti][q] <= e) ? 1u : 0u;
+                tb[k] = s * Pmax;
+                ndv[k] = tab_nd[s];
+                phase_of((int32_t)clk[k], prm, &q1[k], &r1[k]);
+                lo[k] = 0;
             }
-            if (lane == 0) t_nk[ti] = k;
-        }
-    }
-    __syncthreads();
-
-    // ---- the workgroup's kept rows, gathered tile after tile into the front of its block of the kept arrays -------
-    {
-        uint32_t kb[FUSED_TILES + 1];
-        kb[0] = 0;
+            for (uint32_t h = Pmax >> 1; h; h >>= 1) {
 #pragma unroll
-        for (int i = 0; i < FUSED_TILES; i++) kb[i + 1] = kb[i] + t_nk[i];
-        const uint32_t NK = kb[FUSED_TILES];
-        const size_t ob = (size_t)f * out.row_cap + (size_t)c * FUSED_ENTRIES;
-        for (uint32_t q = tid; 4u * q < NK; q += 512) {
-            uint32_t ck[4], rs[4], ub = 0, bb = 0;
-#pragma unroll
-            for (int z = 0; z < 4; z++) {
-                const uint32_t pos = min(4u * q + z, NK - 1u);
-                uint32_t ti = 0;
-#pragma unroll
-                for (int i = 1; i < FUSED_TILES; i++) ti += (kb[i] <= pos) ? 1u : 0u;      // tiles wholly before pos
-                // (empty tiles share their successor's base, so the count lands on the tile that holds pos)
-                uint32_t base = 0;
-#pragma unroll
-                for (int i = 0; i < FUSED_TILES; i++) base = (uint32_t)i == ti ? kb[i] : base;
-                const uint32_t idx = pos - base;
-                const uint32_t *sg = stage[ti];
-                const uint8_t *sg8 = reinterpret_cast<const uint8_t *>(sg + 2 * SLOT_ROWS);
-                ck[z] = sg[idx];
-                rs[z] = sg[SLOT_ROWS + idx];
-                ub |= (uint32_t)sg8[SLOT_ROWS + idx] << (8 * z);
-                bb |= (uint32_t)sg8[2 * SLOT_ROWS + idx] << (8 * z);
+                for (int k = 0; k < FU_CHUNKS; k++) lo[k] += tab[tb[k] + lo[k] + h - 1].x < r1[k] ? h : 0u;
             }
-            *reinterpret_cast<uint4 *>(kout.clk + ob + 4u * q) = make_uint4(ck[0], ck[1], ck[2], ck[3]);
-            *reinterpret_cast<uint4 *>(kout.rss + ob + 4u * q) = make_uint4(rs[0], rs[1], rs[2], rs[3]);
-            *reinterpret_cast<uint32_t *>(kout.ue + ob + 4u * q) = ub;
-            *reinterpret_cast<uint32_t *>(kout.bs + ob + 4u * q) = bb;
-        }
-        if (tid == 0) {
-            kout.slot_cnt[(size_t)f * kout.slot_stride + c] = NK;
-            uint32_t *wc = fw.wg_cnt + pix * FUSED_CNT_WORDS;
-            uint32_t v = 0, d = 0;
-            for (int w = 0; w < FU_WAVES; w++) { v += wave_cnt[w][0]; d += wave_cnt[w][1]; }
-            wc[0] = v; wc[1] = d; wc[2] = NG; wc[3] = NB; wc[4] = NK;
+            uint64_t km[FU_CHUNKS];
+            uint32_t res[FU_CHUNKS];
+#pragma unroll
+            for (int k = 0; k < FU_CHUNKS; k++) {
+                const uint32_t nd = ndv[k], ndm = max(nd, 1u);
+                const bool wrap_s = lo[k] >= nd, wrap_p = lo[k] == 0;
+                const uint32_t is = wrap_s ? 0u : lo[k], ip = wrap_p ? ndm - 1u : lo[k] - 1u;
+                const uint2 es = tab[tb[k] + is], ep = tab[tb[k] + ip];
+                const uint32_t rs_ = es.x + (wrap_s ? cyc : 0u) - r1[k], rp_ = r1[k] + (wrap_p ? cyc : 0u) - ep.x;
+                const bool pd = rp_ < rs_ || (rp_ == rs_ && (ep.y >> 8) < (es.y >> 8));       // ties: the earlier baseline
+                const uint32_t adj = pd ? (wrap_p ? 0xFFFFFFFFu : 0u) : (wrap_s ? 1u : 0u);
+                res[k] = (((pd ? ep.y : es.y) & 0xFFu) + q1[k] + adj) & modm;
+                km[k] = __ballot(cand[k] && nd != 0u && (pd ? rp_ : rs_) <= tol);
+            }
+            wave_lds_fence();                  // every row of the tile is in registers: pack in place
+            uint32_t kept = 0;
+#pragma unroll
+            for (int k = 0; k < FU_CHUNKS; k++) {
+                if ((km[k] >> lane) & 1u) {
+                    const uint32_t o = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(km[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km[k], 0u));
+                    stg[o] = clk[k];
+                    stg[SLOT_ROWS + o] = rss[k];
+                    stg8[SLOT_ROWS + o] = (uint8_t)uev[k];
+                    stg8[2 * SLOT_ROWS + o] = (uint8_t)res[k];
+                }
+                kept += (uint32_t)__popcll(km[k]);
+            }
+            wave_lds_fence();
+            if (!(FU_EXP & 1)) {
+                constexpr uint32_t Q = SLOT_ROWS / 4;
+                const size_t ob = (size_t)f * out.row_cap + (size_t)t * SLOT_ROWS;
+                const uint32_t nq = (kept + 3u) >> 2;
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(stg);
+                const uint32_t *s1 = stg + 2 * SLOT_ROWS;             // flag dwords [0, Q), ue [Q, 2Q), corrected bs [2Q, 3Q)
+                uint4 *gc = reinterpret_cast<uint4 *>(kout.clk + ob), *gr = reinterpret_cast<uint4 *>(kout.rss + ob);
+                uint32_t *gu = reinterpret_cast<uint32_t *>(kout.ue + ob), *gb = reinterpret_cast<uint32_t *>(kout.bs + ob);
+                if (lane < nq) {
+                    gc[lane] = s4[lane];
+                    gr[lane] = s4[Q + lane];
+                    gu[lane] = s1[Q + lane];
+                    gb[lane] = s1[2 * Q + lane];
+                }
+                if (64u + lane < nq) {
+                    gc[64 + lane] = s4[64 + lane];
+                    gr[64 + lane] = s4[Q + 64 + lane];
+                    gu[64 + lane] = s1[Q + 64 + lane];
+                    gb[64 + lane] = s1[2 * Q + 64 + lane];
+                }
+            }
+            if (lane == 0) kout.slot_cnt[(size_t)f * kout.slot_stride + t] = kept;
         }
     }
 }
@@ -664,12 +666,13 @@ __global__ __launch_bounds__(256) void k_fused_finish(uint32_t F, uint32_t *stat
             if (!redo) {
                 st[SLAM_STAT_GROUPS] = g;
                 st[SLAM_STAT_BASELINES] = b;
-                st[SLAM_STAT_LAYOUT] = SLAM_LAYOUT_KEPT_GROUPS;
+                st[SLAM_STAT_LAYOUT] = SLAM_LAYOUT_KEPT_TILES;
             }
         }
     }
     if (lane == 0) {
         fw.redo[f] = redo ? 1u : 0u;
+        if (fw.fail[f]) st[SLAM_STAT_LAYOUT] |= fw.fail[f] << SLAM_LAYOUT_FUSED_WHY_SHIFT;      // diagnostic: why the frame was handed on
         if (loose) {
             st[SLAM_STAT_VALID] = 0;
             st[SLAM_STAT_DISCARDED] = 0;

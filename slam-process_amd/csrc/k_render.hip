@@ -61,8 +61,8 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
     const uint32_t n = stats[f * SLAM_STAT_WORDS + stat_word];
     const uint32_t r0 = blockIdx.x * PIVOT_CHUNK;
     if (r0 >= n) return;
-    // slotted rows: per ROWS_PER_BLOCK entries, or per fused workgroup where the fused kernel served the frame
-    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_GROUPS) ? (uint32_t)FUSED_ENTRIES : (uint32_t)ROWS_PER_BLOCK;
+    // slotted rows: per ROWS_PER_BLOCK entries, or per tile where the fused kernel served the frame
+    const uint32_t unit = (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_KEPT_TILES) ? (uint32_t)SLOT_ROWS : (uint32_t)ROWS_PER_BLOCK;
     const uint32_t r1 = min(n, r0 + PIVOT_CHUNK);
     for (int i = tid; i < N_BEAMS * LSTRIDE; i += 1024) acc[i] = 0;
     if (tid < N_BEAMS) b2a[tid] = beam_to_axis[tid];

@@ -153,18 +153,18 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
 // One kernel takes text to records AND corrected rows: a workgroup decodes FUSED_TILES consecutive framing tiles,
 // keeps their rows in LDS, exchanges the baselines of the sweeps that cross its borders with the neighbouring
 // workgroups (published through `pub`, signalled through `flag`) and corrects its rows there.  Kept rows of such a
-// frame are slotted per workgroup: the rows kept among entries [w*FUSED_ENTRIES, (w+1)*FUSED_ENTRIES) sit at the
-// front of the same entries, kept slot_cnt[f*slot_stride + w] of them.  A frame the kernel cannot finish (see
+// frame are slotted per tile like the decoded rows: the rows kept among tile t's entries sit at the front of the
+// same entries of the kept arrays, slot_cnt[f*slot_stride + t] of them.  A frame the kernel cannot finish (see
 // k_fused.hip) is flagged in `fail` and corrected by the separate kernels, which `redo` gates.
-constexpr int FUSED_TILES = SLAM_KEPT_GROUP_TILES;
+constexpr int FUSED_TILES = 16;                  // framing tiles a workgroup decodes and corrects
 constexpr int FUSED_ENTRIES = FUSED_TILES * SLOT_ROWS;
-constexpr int FUSED_PUB_WORDS = 256;             // 8-byte words a workgroup publishes: header + baselines of its two border sweeps
-constexpr int FUSED_CNT_WORDS = 8;               // per workgroup: valid, discarded, groups, baselines, kept
+constexpr int FUSED_PUB_WORDS = 256;             // 8-byte words a workgroup publishes: the baselines of its two border sweeps
+constexpr int FUSED_CNT_WORDS = 4;               // per workgroup: valid, discarded, groups, baselines
 struct fused_ws {
-    uint32_t *flag = nullptr;                    // [F * wg_stride] 1 = published (zeroed before every launch)
+    uint32_t *flag = nullptr;                    // [F * wg_stride] the header word a workgroup publishes, 0 = not yet (zeroed before every launch)
     unsigned long long *pub = nullptr;           // [F * wg_stride * FUSED_PUB_WORDS]
     uint32_t *wg_cnt = nullptr;                  // [F * wg_stride * FUSED_CNT_WORDS]
-    uint32_t *fail = nullptr;                    // [F] nonzero: the fused kernel gave the frame up (zeroed before every launch)
+    uint32_t *fail = nullptr;                    // [F] nonzero (SLAM_FUSED_GAVE_UP_* bits): the fused kernel gave the frame up (zeroed before every launch)
     uint32_t *redo = nullptr;                    // [F] nonzero: the separate correction kernels serve the frame
     uint32_t wg_stride = 0;
     static uint32_t wgs_for(uint32_t st_max) { return (st_max + FUSED_TILES - 1) / FUSED_TILES; }

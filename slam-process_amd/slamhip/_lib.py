@@ -20,14 +20,17 @@ STAT_WORDS = 16
 (STAT_NBYTES, STAT_NOT_STRICT, STAT_VALID, STAT_DISCARDED, STAT_GROUPS, STAT_BASELINES, STAT_KEPT,
  STAT_N_AOD, STAT_N_AOA, STAT_ALLNAN, STAT_VMIN_LO, STAT_VMIN_HI, STAT_VMAX_LO, STAT_VMAX_HI,
  STAT_ROW_SLOTS, STAT_LAYOUT) = range(16)
-LAYOUT_TWO_PASS, LAYOUT_KEPT_GROUPS = 1, 2
-TILE_BYTES, TILE_SLOTS, KEPT_BLOCK, KEPT_GROUP_TILES = 3024, 276, 1024, 16
-ABI_REVISION = 3                      # SLAM_ABI_REVISION of the header this binding was written against
+LAYOUT_TWO_PASS, LAYOUT_KEPT_TILES, LAYOUT_FUSED_WHY_SHIFT = 1, 2, 8
+# SLAM_FUSED_GAVE_UP_*: why the fused decode + correct kernel handed a frame on (layout word >> LAYOUT_FUSED_WHY_SHIFT)
+(FUSED_GAVE_UP_TILE_LISTS, FUSED_GAVE_UP_UNSYNC, FUSED_GAVE_UP_FIRST_ROW, FUSED_GAVE_UP_WG_LISTS, FUSED_GAVE_UP_TIMEOUT,
+ FUSED_GAVE_UP_NEIGHBOUR, FUSED_GAVE_UP_GROUP_SIZE) = 1, 2, 4, 8, 16, 32, 64
+TILE_BYTES, TILE_SLOTS, KEPT_BLOCK = 3024, 276, 1024
+ABI_REVISION = 4                      # SLAM_ABI_REVISION of the header this binding was written against
 
 
 def kept_unit(layout_word: int) -> int:
     """Entries per block of a frame's corrected-row arrays, from its SLAM_STAT_LAYOUT word."""
-    return KEPT_GROUP_TILES * TILE_SLOTS if int(layout_word) & LAYOUT_KEPT_GROUPS else KEPT_BLOCK
+    return TILE_SLOTS if int(layout_word) & LAYOUT_KEPT_TILES else KEPT_BLOCK
 NOALLOC_SCRATCH_BYTES = 64 << 20
 MAX_AXIS = 256
 
@@ -40,7 +43,7 @@ EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version", "slam_abi_revision", "slam_set_fused", "slam_get_fused",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean", "slam_pivot_mean_f64",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
-    "slam_row_tiles", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
+    "slam_row_tiles", "slam_kept_blocks", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
 ]
 
@@ -138,12 +141,14 @@ def load() -> C.CDLL:
         lib.slam_read_probe_dev.argtypes = [vp, vp, vp, sz, C.c_int]
         lib.slam_row_tiles.argtypes = [u32, u32]
         lib.slam_row_tiles.restype = u32
+        lib.slam_kept_blocks.argtypes = [u32, u32, u32]
+        lib.slam_kept_blocks.restype = u32
         lib.slam_timing_enable.argtypes = [vp, C.c_int]
         lib.slam_timing_reset.argtypes = [vp]
         lib.slam_timing_read.argtypes = [vp, vp, vp, vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len", "slam_row_tiles", "slam_cells_per_frame"):
+            if name not in ("slam_last_error", "slam_version", "slam_synth_text_len", "slam_row_tiles", "slam_kept_blocks", "slam_cells_per_frame"):
                 fn.restype = C.c_int
         _lib = lib
         return lib

@@ -76,7 +76,7 @@ class FramePipeline:
         self.rss = torch.empty(F * rc, dtype=u32, device=d)
         self.clk = torch.empty(F * rc, dtype=u32, device=d)
         self.tile_cnt = torch.zeros(F * self.row_tiles, dtype=u32, device=d)
-        self.kept_blocks = (rc + _lib.KEPT_BLOCK - 1) // _lib.KEPT_BLOCK
+        self.kept_blocks = int(self.ctx.lib.slam_kept_blocks(rc, self.max_text_len, 1 if src_is_bytes else 0))
         self.kept_cnt = torch.zeros(F * self.kept_blocks, dtype=u32, device=d)
         self.k_ue = torch.empty(F * rc, dtype=u8, device=d)
         self.k_bs = torch.empty(F * rc, dtype=u8, device=d)

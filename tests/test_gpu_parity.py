@@ -343,7 +343,7 @@ def test_synth_device_matches_numpy():
 @pytest.mark.parametrize("shape", [(8, 256, 3), (16, 1024, 2), (4, 4096, 2)])
 def test_batched_pipeline_against_oracle(mapping, lut, shape, two_pass, monkeypatch, _kernel_mode):
     import torch
-    from slamhip import synth
+    from slamhip import _lib, synth
     from slamhip.pipeline import FramePipeline, synth_frames
     B, N, F = shape
     if two_pass:                       # every frame through the fallback the single-pass kernel hands over to
@@ -360,10 +360,13 @@ def test_batched_pipeline_against_oracle(mapping, lut, shape, two_pass, monkeypa
     for f in range(F):
         by = synth.make_frame_bytes(B, N, f)
         assert st[f, 0] == len(by) and st[f, 1] == 0
-        # layout word: decoded by the two-pass kernels or not; kept rows per fused workgroup where the fused kernel served the frame
-        # (eight sweeps of 256 rows start inside one workgroup of the fused kernel: one more than it takes, so it hands that shape on)
+        # layout word: decoded by the two-pass kernels or not; kept rows per tile where the fused kernel served the frame
+        # (eight sweeps of 256 rows start inside one workgroup of the fused kernel: one more than it takes, so it hands that
+        # shape on and says why in the word's upper bits)
         served = _kernel_mode == "fused" and shape != (8, 256, 3)
-        assert int(st[f, 15]) == (1 if two_pass else (2 if served else 0))
+        assert int(st[f, 15]) & 0xFF == (1 if two_pass else (2 if served else 0))
+        gave_up = _kernel_mode == "fused" and not two_pass and not served
+        assert int(st[f, 15]) >> _lib.LAYOUT_FUSED_WHY_SHIFT == (_lib.FUSED_GAVE_UP_WG_LISTS if gave_up else 0)
         rows_o, v, d = O.parse_groups(by)
         assert (int(st[f, 2]), int(st[f, 3])) == (v, d)
         rows = pipe.frame_rows(f, st)
