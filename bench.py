@@ -59,6 +59,7 @@ def parse_args():
     p.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU-oracle sample (0 = skip)")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-other-configs", action="store_true", help="N=1: skip the short passes over the other shapes")
+    p.add_argument("--no-pcie-fed", action="store_true", help="N=1: skip the host-fed rate measured after the clock")
     p.add_argument("--fused", type=int, choices=(0, 1), default=None,
                    help="decode + correction as one fused kernel (1) or as separate kernels (0); default: the library's")
     p.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -153,6 +154,54 @@ def measured_ceilings(ctx, pipe, achieved_gbs):
                 probe_bytes=n, frac_of_read3_write1=round(achieved_gbs / mix, 4))
 
 
+def pcie_fed(pipe, text, stride, tl, dev, frames=64, batches=6):
+    """After the clock, never part of `value`: the same pipeline fed over PCIe.  `frames` frames of text sit in pinned
+    host memory and are copied batch by batch into two device buffers on a copy stream while the batch before is
+    processed on a compute stream; also the plain host-to-device copy rate of the same buffer."""
+    F_all = pipe.bt.n_frames
+    frames = min(frames, F_all, text.numel() // stride // 2)
+    if frames < 1:
+        return None
+    n = frames * stride
+    host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    host.copy_(text[:n])
+    bufs = [text[:n], text[n:2 * n]]
+    pipe.set_uniform_layout(frames, stride, tl)
+    copy_s, comp_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def run(k):
+        for i in range(k):
+            j = i & 1
+            with torch.cuda.stream(copy_s):
+                if i >= 2:
+                    copy_s.wait_event(freed[j])
+                bufs[j].copy_(host, non_blocking=True)
+                ready[j].record(copy_s)
+            with torch.cuda.stream(comp_s):
+                comp_s.wait_event(ready[j])
+                pipe.run(text, text_base_offset=j * n)
+                freed[j].record(comp_s)
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)
+    run(3)
+    t0 = time.perf_counter()
+    run(batches)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(4):
+        bufs[0].copy_(host, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    link = 4 * n / (time.perf_counter() - t1) / 1e9
+    pipe.set_uniform_layout(F_all, stride, tl)
+    del host
+    return dict(frames_per_s=round(frames * batches / dt, 1), h2d_GBps=round(link, 1), frames_per_batch=frames, batches=batches,
+                note="text in pinned host memory, copied batch by batch on a copy stream while the batch before computes; "
+                     "measured after the timed region, never part of `value`")
+
+
 # The three builds of the fused correction kernel share one job: frames (or workgroups) the lean build leaves go to
 # the mid or the full one, so their times add up against one set of algorithmic bytes.
 KERNEL_GROUPS = {"rows_finish": ("rows_finish", "rows_finish_mid", "rows_finish_rest")}
@@ -229,18 +278,20 @@ class Job:
         self.local = local % max(1, torch.cuda.device_count())          # ranks share GPUs only in a --backend gloo rehearsal
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
-        self.ranks_seen, self.comm_version = 1, None
+        self.ranks_seen, self.comm_version, self.comm_name = 1, None, None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
             if a.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
+                self.comm_name = "RCCL over xGMI"
                 try:
                     self.comm_version = "rccl/nccl " + ".".join(str(x) for x in torch.cuda.nccl.version())
                 except Exception as e:               # noqa: BLE001
                     self.comm_version = f"nccl (version unavailable: {e})"
             else:
                 dist.init_process_group("gloo")
+                self.comm_name = "gloo, staged through host memory: a rehearsal, not RCCL"
                 self.comm_version = "gloo (host-staged rehearsal)"
             ones = torch.ones(1, dtype=torch.int64, device=self.dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(ones)                      # every rank the process group really holds adds one
@@ -345,14 +396,20 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
         if with_timing:
             ctx.timing_reset()
             ctx.timing(True)
+        # one event per step boundary on the compute stream (recording costs nothing to speak of): the spread of the
+        # K step times tells a change of a few per cent from the noise of a box
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
         job.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        marks[0].record(torch.cuda.current_stream(dev))
         for i in range(K):
             step(W + i)
+            marks[i + 1].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         job.barrier()
         t1 = time.perf_counter()
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(K)]
         kern = {}
         if with_timing:
             ctx.timing(False)
@@ -371,13 +428,13 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
         if world > 1:
             dt = job.reduce_scalar(dt, job.dist.ReduceOp.MAX)
         del recv
-        return dt, kern, verified
+        return dt, kern, verified, step_ms
 
-    dt, kern, verified = run_mode(gmode, timing)
+    dt, kern, verified, step_ms = run_mode(gmode, timing)
     gather_rates = {gmode: dict(frames_per_s=round(K * F * world / dt, 2), ms_per_step=round(dt / K * 1e3, 4),
                                 gather_verified=verified)}
     for m in modes[1:]:                                      # the other gather mode(s), after the headline's clock
-        dt2, _k, ver2 = run_mode(m, False)
+        dt2, _k, ver2, _s = run_mode(m, False)
         gather_rates[m] = dict(frames_per_s=round(K * F * world / dt2, 2), ms_per_step=round(dt2 / K * 1e3, 4),
                                gather_verified=ver2)
 
@@ -402,6 +459,9 @@ def measure(job, B, N, F, K, W, n_distinct_want, tile, upscale, gmode, timing, e
     why = {int(w): int((why == w).sum()) for w in np.unique(why) if w}
     res = dict(value=fps_rank * world, ms_per_step=dt / K * 1e3, F=F, n_distinct=n_distinct, tl=tl, kappa=kappa,
                fused=pipe.ctx.get_fused(), fused_frames=served, fused_gave_up=why,
+               step_ms=dict(min=round(min(step_ms), 4), median=round(float(np.median(step_ms)), 4), max=round(max(step_ms), 4),
+                            slowest_step=int(np.argmax(step_ms)), all=[round(x, 3) for x in step_ms] if len(step_ms) <= 40 else None,
+                            note="this rank's compute stream, one HIP event per step boundary inside the timed region"),
                alg_frame=alg_frame, fps_rank=fps_rank, kernels=table, roofline=roof, achieved=ach,
                gather_verified=verified, gather_rates=gather_rates if world > 1 else None)
     return res, pipe, text
@@ -436,8 +496,11 @@ def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if world > 1 and a.gpus == 1:
+        a.gpus = world                      # started under torchrun without --gpus: the launcher's world size counts
+    if world != a.gpus and "WORLD_SIZE" in os.environ:
+        print(f"bench: --gpus {a.gpus} but the launcher started {world} rank(s); no line printed", file=sys.stderr)
+        sys.exit(3)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly with --gpus N: run the N ranks as a child job (nothing here has touched the GPU yet)
         import socket
@@ -452,6 +515,9 @@ def main():
     if rank == 0 and a.cpu_frames > 0:      # rank 0 of any world size, before anything here initialises the GPU
         cpu_line = cpu_baseline(a.beams, a.samples, a.cpu_frames, a.tile)
     job = Job(a)
+    if job.ranks_seen != a.gpus:            # a rank that never joined: a line over fewer GPUs than asked for would be wrong
+        print(f"bench: the process group holds {job.ranks_seen} rank(s), --gpus asked for {a.gpus}; no line printed", file=sys.stderr)
+        sys.exit(3)
     B, N, K, W = a.beams, a.samples, a.steps, a.warmup
     gmode = "none" if (world == 1 or a.no_gather) else a.gather
     extra = ()
@@ -471,6 +537,14 @@ def main():
     if roof is not None and rank == 0:
         roof["measured_ceilings"] = measured_ceilings(pipe.ctx, pipe, res["achieved"])
 
+    fed = None
+    if world == 1 and not a.no_pcie_fed and rank == 0:
+        try:
+            stride = ((res["tl"] + 255) // 256) * 256
+            fed = pcie_fed(pipe, text, stride, res["tl"], job.dev)
+        except Exception as e:                   # noqa: BLE001  (the headline line must still be printed)
+            fed = dict(error=f"{type(e).__name__}: {e}")
+
     other = None
     if world == 1 and not a.no_other_configs and (B, N, a.upscale) == (256, 4096, 1) and not a.no_kernel_timing:
         # short passes over the other two synthetic shapes the benchmark is specified for, after the headline region;
@@ -489,7 +563,7 @@ def main():
     out = {
         "metric": "frames/s (256-beam x 4096-sample decode+correct+raster)",
         "value": round(res["value"], 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(res["ms_per_step"], 4), "step_ms": res["step_ms"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"synthetic {B}x{N} hex frames ({records} records, {res['tl']} text bytes each), "
                                f"{F} frames/step, {res['n_distinct']} distinct frames resident in HBM per GPU, "
@@ -499,9 +573,9 @@ def main():
                                      (f" ({res['fused_frames']} of {F} frames of the last batch served by it" +
                                       (f"; handed on, by reason bits: {res['fused_gave_up']}" if res["fused_gave_up"] else "") + ")" if res["fused"] else ""),
                    "parallelism": f"frames sharded over {world} GPU(s)" +
-                                  {"none": "", "tiles": ", 4 MiB tiles gathered to rank 0 every step (RCCL)",
+                                  {"none": "", "tiles": f", 4 MiB tiles gathered to rank 0 every step ({job.comm_name})",
                                    "compact": ", tiles gathered to rank 0 every step in compact form (cell colours + "
-                                              "pixel maps, repainted bit-exactly by slam_raster_dev; RCCL)"}[gmode],
+                                              f"pixel maps, repainted bit-exactly by slam_raster_dev; {job.comm_name})"}[gmode],
                    "gather": gmode, "gather_verified": res["gather_verified"], "gather_rates": res["gather_rates"],
                    "ranks_seen": job.ranks_seen, "comm": job.comm_version},
         "kappa_kept_ratio": round(res["kappa"], 4),
@@ -509,6 +583,7 @@ def main():
         "pipeline_alg_GBps": round(res["fps_rank"] * res["alg_frame"] / 1e9, 1),
         "pipeline_hbm_frac": round(res["fps_rank"] * res["alg_frame"] / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roof,
+        "pcie_fed": fed,
         "kernels": res["kernels"],
         "other_configs": other,
     }

@@ -393,6 +393,47 @@ def pivot_mean_float(ue, bs, rss, mapping: Dict[int, float]):
     return full[np.ix_(rows, cols)], angles[rows].tolist(), angles[cols].tolist(), s, c
 
 
+def pivot_mean_float_lockstep(ue, bs, rss, mapping: Dict[int, float]):
+    """pivot_mean_float for large tables: the same recurrence, but the rows are first brought together cell by cell in
+    row order (stable argsort) and step k adds the k-th value of every cell at once.  Same bits as the row-by-row loop
+    (tests/test_oracle_golden.py holds the two against each other); returns the same tuple."""
+    b2a, angles = axis_from_mapping(mapping)
+    n_axis = len(angles)
+    u, b = _i64(ue), _i64(bs)
+    r = np.ascontiguousarray(np.asarray(rss), dtype=np.float64)
+    ok = (u >= 0) & (u <= 63) & (b >= 0) & (b <= 63) & ~np.isnan(r)
+    col = np.where(ok, b2a[np.clip(u, 0, 63)], -1).astype(np.int64)
+    row = np.where(ok, b2a[np.clip(b, 0, 63)], -1).astype(np.int64)
+    ok &= (col >= 0) & (row >= 0)
+    cell = (row * n_axis + col)[ok]
+    vals = r[ok]
+    order = np.argsort(cell, kind="stable")
+    cell, vals = cell[order], vals[order]
+    cnt = np.bincount(cell, minlength=n_axis * n_axis).astype(np.int64)
+    start = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+    s = np.zeros(n_axis * n_axis, np.float64)
+    comp = np.zeros(n_axis * n_axis, np.float64)
+    live = np.flatnonzero(cnt > 0)
+    k = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        while len(live):
+            v = vals[start[live] + k]
+            y = v - comp[live]
+            t = s[live] + y
+            cc = (t - s[live]) - y
+            comp[live] = np.where(np.isnan(cc), 0.0, cc)
+            s[live] = t
+            k += 1
+            live = live[cnt[live] > k]
+    s = s.reshape(n_axis, n_axis)
+    c = cnt.reshape(n_axis, n_axis)
+    rows = np.flatnonzero(c.sum(axis=1) > 0)
+    cols = np.flatnonzero(c.sum(axis=0) > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        full = np.where(c > 0, s / np.maximum(c, 1), np.nan)
+    return full[np.ix_(rows, cols)], angles[rows].tolist(), angles[cols].tolist(), s, c
+
+
 # ---------------------------------------------------------------------------
 # a11-a12  gaussian_kernel (:320-333), gaussian_blur_nan_aware (:336-368)
 # ---------------------------------------------------------------------------

@@ -716,8 +716,10 @@ extern "C" int slam_pivot_mean_f64(slam_ctx *ctx, const int32_t *ue, const int32
                              beam_to_axis[i], n_axis);
     const size_t cells = (size_t)n_axis * n_axis;
     ws_plan p;
-    const size_t ou = p.add(n * 4 + 4), ob = p.add(n * 4 + 4), orr = p.add(n * 8 + 8), oc = p.add(n * 4 + 4),
+    const size_t ou = p.add(n * 4 + 4), ob = p.add(n * 4 + 4), orr = p.add(n * 8 + 8),
                  ob2a = p.add(64 * sizeof(int16_t)), os = p.add(cells * 8), ok = p.add(cells * 4), om = p.add(cells * 8);
+    pivot_kahan_ws kw;
+    kw.plan(p, (uint32_t)n, n_axis);
     SLAM_TRY(slam_ws_reserve(ctx, p.total));
     uint8_t *b = ctx->ws;
     SLAM_TRY(h2d(ctx, b + ou, ue, n * 4));
@@ -725,7 +727,7 @@ extern "C" int slam_pivot_mean_f64(slam_ctx *ctx, const int32_t *ue, const int32
     SLAM_TRY(h2d(ctx, b + orr, rss, n * 8));
     SLAM_TRY(h2d(ctx, b + ob2a, beam_to_axis, 64 * sizeof(int16_t)));
     SLAM_TRY(pivot_kahan(ctx, (const int32_t *)(b + ou), (const int32_t *)(b + ob), (const double *)(b + orr), (uint32_t)n,
-                         (const int16_t *)(b + ob2a), n_axis, (int32_t *)(b + oc), (double *)(b + os), (uint32_t *)(b + ok),
+                         (const int16_t *)(b + ob2a), n_axis, b, kw, (double *)(b + os), (uint32_t *)(b + ok),
                          (double *)(b + om)));
     std::vector<uint32_t> c32(cells);
     if (sum) SLAM_TRY(d2h(ctx, sum, b + os, cells * 8));

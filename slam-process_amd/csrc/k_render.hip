@@ -131,48 +131,56 @@ __global__ __launch_bounds__(1024) void k_pivot(const T8 *ue, const T8 *bs, cons
 // ---- pivot of real-valued RSS ---------------------------------------------------------------------------------
 // pandas' pivot_table(aggfunc=mean) (compute_rssi_matrix, excel_heatmap_v3.py:297-299) sums every cell's values in
 // row order with Kahan compensation and divides by the count; for values that are not integers the result depends
-// on that order, so it is followed literally: k_cell_index gives every row its cell, then one wave per cell walks
-// the rows in order, finds its own by ballot and adds them one after the other.
+// on that order, so it is followed literally: k_cell_index gives every row its cell, a stable sort by cell
+// (sort_cells) brings each cell's values together in row order, k_cell_bounds finds where each cell's run starts and
+// ends, and one wave per cell adds its run up one value after the other.  Work grows with rows + cells, not with
+// their product.
 __global__ __launch_bounds__(256) void k_cell_index(const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
-                                                     const int16_t *beam_to_axis, int n_axis, int32_t *cell)
+                                                     const int16_t *beam_to_axis, int n_axis, uint32_t *cell)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int32_t u = ue[i], b = bs[i];
-    int32_t c = -1;
+    uint32_t c = (uint32_t)(n_axis * n_axis);                                 // no cell: sorts behind every cell
     if (u >= 0 && u <= 63 && b >= 0 && b <= 63 && !isnan(rss[i])) {          // validate_beam_id; NaN values are not counted
         const int cc = beam_to_axis[u], rr = beam_to_axis[b];
-        if ((uint32_t)cc < (uint32_t)n_axis && (uint32_t)rr < (uint32_t)n_axis) c = rr * n_axis + cc;
+        if ((uint32_t)cc < (uint32_t)n_axis && (uint32_t)rr < (uint32_t)n_axis) c = (uint32_t)(rr * n_axis + cc);
     }
     cell[i] = c;
 }
 
-__global__ __launch_bounds__(256) void k_pivot_kahan(const int32_t *cell, const double *rss, uint32_t n, int cells,
+// sorted cells -> [begin, end) of every cell's run (cells without rows keep the zeros they were cleared to)
+__global__ __launch_bounds__(256) void k_cell_bounds(const uint32_t *cell, uint32_t n, uint32_t cells, uint32_t *begin, uint32_t *end)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cell[i];
+    if (c >= cells) return;
+    if (i == 0 || cell[i - 1] != c) begin[c] = i;
+    if (i + 1 == n || cell[i + 1] != c) end[c] = i + 1;
+}
+
+__global__ __launch_bounds__(256) void k_pivot_kahan(const double *val, const uint32_t *begin, const uint32_t *end, int cells,
                                                       double *sum, uint32_t *cnt, double *mean)
 {
     const int mine = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (mine >= cells) return;
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_id(), b0 = begin[mine], e0 = end[mine];
     double s = 0.0, comp = 0.0;
-    uint32_t k = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
-        const bool hit = i < n && cell[i] == mine;
-        const double v = hit ? rss[i] : 0.0;
-        uint64_t m = __ballot(hit);
-        while (m) {                                       // the cell's rows of this stretch, in row order
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const double val = __longlong_as_double((long long)shfl64((uint64_t)__double_as_longlong(v), src));
-            const double y = val - comp;
+    for (uint32_t base = b0; base < e0; base += 64) {
+        const uint32_t m = min(64u, e0 - base);
+        const double v = lane < m ? val[base + lane] : 0.0;       // the cell's next values, in row order
+        for (uint32_t j = 0; j < m; j++) {
+            const double x = __longlong_as_double((long long)shfl64((uint64_t)__double_as_longlong(v), (int)j));
+            const double y = x - comp;
             const double t = s + y;
             comp = (t - s) - y;
             if (comp != comp) comp = 0.0;                 // an infinite sum leaves no compensation
             s = t;
-            k++;
         }
     }
     if (lane == 0) {
+        const uint32_t k = e0 - b0;
         if (sum) sum[mine] = s;
         if (cnt) cnt[mine] = k;
         mean[mine] = k ? s / (double)k : __longlong_as_double(0x7FF8000000000000ll);
@@ -842,12 +850,36 @@ int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, cons
     return SLAM_OK;
 }
 
+size_t pivot_kahan_ws::plan(ws_plan &p, uint32_t n, int n_axis)
+{
+    const size_t cells = (size_t)n_axis * n_axis;
+    unsigned b = 1;
+    while ((1ull << b) <= cells) b++;                     // keys 0 .. cells (the last one: no cell)
+    bits = b;
+    o_key = p.add((size_t)n * 4 + 4);
+    o_key2 = p.add((size_t)n * 4 + 4);
+    o_val2 = p.add((size_t)n * 8 + 8);
+    o_bounds = p.add(cells * 2 * 4);
+    tmp_bytes = n ? sort_cells_temp_bytes(n, bits) : 0;
+    o_tmp = p.add(tmp_bytes + 16);
+    return p.total;
+}
+
 int pivot_kahan(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
-                const int16_t *beam_to_axis, int n_axis, int32_t *cell, double *sum, uint32_t *cnt, double *mean)
+                const int16_t *beam_to_axis, int n_axis, uint8_t *ws, const pivot_kahan_ws &w, double *sum, uint32_t *cnt,
+                double *mean)
 {
     const int cells = n_axis * n_axis;
-    if (n) SLAM_LAUNCH(ctx, "cell_index", k_cell_index, dim3((n + 255) / 256), dim3(256), ue, bs, rss, n, beam_to_axis, n_axis, cell);
-    SLAM_LAUNCH(ctx, "pivot_kahan", k_pivot_kahan, dim3((cells + 3) / 4), dim3(256), cell, rss, n, cells, sum, cnt, mean);
+    uint32_t *key = (uint32_t *)(ws + w.o_key), *key2 = (uint32_t *)(ws + w.o_key2), *begin = (uint32_t *)(ws + w.o_bounds),
+             *end = begin + cells;
+    double *val2 = (double *)(ws + w.o_val2);
+    SLAM_TRY(slam_zero_async(ctx, begin, (size_t)cells * 2 * 4));
+    if (n) {
+        SLAM_LAUNCH(ctx, "cell_index", k_cell_index, dim3((n + 255) / 256), dim3(256), ue, bs, rss, n, beam_to_axis, n_axis, key);
+        SLAM_TRY(sort_cells(ctx, ws + w.o_tmp, w.tmp_bytes, key, key2, rss, val2, n, w.bits));
+        SLAM_LAUNCH(ctx, "cell_bounds", k_cell_bounds, dim3((n + 255) / 256), dim3(256), key2, n, (uint32_t)cells, begin, end);
+    }
+    SLAM_LAUNCH(ctx, "pivot_kahan", k_pivot_kahan, dim3((cells + 3) / 4), dim3(256), val2, begin, end, cells, sum, cnt, mean);
     return SLAM_OK;
 }
 

@@ -228,9 +228,19 @@ int matrix_blur_render(slam_ctx *ctx, uint32_t F, const render_params &rp, const
 
 // standalone small-matrix stages used by slam_pivot_mean / slam_blur_nan / slam_render (device pointers)
 int mean_only(slam_ctx *ctx, const unsigned long long *sum, const uint32_t *cnt, int cells, double *matrix);
-// real-valued RSS: per cell the Kahan sum in row order, the count and the mean (cell: n int32 of scratch)
+// real-valued RSS: per cell the Kahan sum in row order, the count and the mean.  The rows are brought together cell by
+// cell with a stable sort (k_sort.hip); `ws` holds the scratch pivot_kahan_ws::plan laid out.
+struct pivot_kahan_ws {
+    size_t o_key = 0, o_key2 = 0, o_val2 = 0, o_bounds = 0, o_tmp = 0, tmp_bytes = 0;
+    unsigned bits = 0;
+    size_t plan(ws_plan &p, uint32_t n, int n_axis);
+};
 int pivot_kahan(slam_ctx *ctx, const int32_t *ue, const int32_t *bs, const double *rss, uint32_t n,
-                const int16_t *beam_to_axis, int n_axis, int32_t *cell, double *sum, uint32_t *cnt, double *mean);
+                const int16_t *beam_to_axis, int n_axis, uint8_t *ws, const pivot_kahan_ws &w, double *sum, uint32_t *cnt,
+                double *mean);
+size_t sort_cells_temp_bytes(uint32_t n, unsigned bits);
+int sort_cells(slam_ctx *ctx, void *tmp, size_t tmp_bytes, const uint32_t *key_in, uint32_t *key_out, const double *val_in,
+               double *val_out, uint32_t n, unsigned bits);
 int blur_only(slam_ctx *ctx, const double *in, int h, int w, const double *kern, int ks, double *out);
 int render_only(slam_ctx *ctx, const double *mat, int h, int w, const double *aod, const double *aoa, int use_log,
                 double vmin, double vmax, const uint8_t *lut, uint8_t *cells, uint8_t *tile, int W, int H,

@@ -78,6 +78,8 @@ def write_report(per_file: Dict[str, List[Dict[str, object]]], path: str) -> Non
         kernels = per_file[src]
         plain = _demangle([str(k["name"]) for k in kernels])
         for k, p in zip(kernels, plain):
+            if "rocprim::" in p:          # kernels of the library sort (k_sort.hip): not ours to report
+                continue
             p = re.sub(r"\(anonymous namespace\)::", "", p)
             p = re.sub(r"^void ", "", p)
             p = p.split("(")[0] if "<" not in p else p[:p.index(">(") + 1] if ">(" in p else p
@@ -120,7 +122,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             rest = [ln for ln in r.stderr.splitlines()
                     if "kernel-resource-usage" not in ln and not re.match(r"^\s*(\d+ \|.*|\|\s*\^.*)?$", ln)]
-            if rest:
+            if any("warning:" in ln or "error:" in ln for ln in rest):      # (include chains of the remarks alone: nothing to say)
                 sys.stderr.write("\n".join(rest) + "\n")
         return obj
 

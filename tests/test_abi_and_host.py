@@ -248,6 +248,85 @@ dist.destroy_process_group()
     assert (tmp_path / "ok").exists()
 
 
+def test_sharding_and_gather_order_eight_ranks_gloo(tmp_path):
+    """world_size 8 on CPU (gloo), the size of the node the benchmark is specified for: frames dealt out by
+    shard_frames and files dealt out by balance_files come back from gather_tiles in the right order, every frame and
+    every file exactly once, with frame counts and file counts that do not divide by the number of ranks."""
+    script = tmp_path / "w8.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {PKG!r})
+import torch, torch.distributed as dist
+from slamhip import dist as D
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+H, W = 3, 5
+def tile_of(f):
+    return (torch.arange(H * W * 4, dtype=torch.int64).reshape(H, W, 4) * (7 * f + 3) % 253).to(torch.uint8)
+# --- frames: f -> rank f mod 8
+for n_frames in (29, 8, 5):
+    mine = D.shard_frames(n_frames, rank, world)
+    assert all(f % world == rank for f in mine)
+    per = (n_frames + world - 1) // world
+    tiles = torch.zeros((per, H, W, 4), dtype=torch.uint8)
+    for i, f in enumerate(mine):
+        tiles[i] = tile_of(f)
+    got = D.gather_tiles(tiles, dst=0)
+    if rank == 0:
+        full = D.interleave_gathered(got, n_frames)
+        assert torch.equal(full, torch.stack([tile_of(f) for f in range(n_frames)])), n_frames
+    else:
+        assert got is None
+# --- files: the 19 capture sizes of the reference's debugDoc (bytes), greedy by size
+sizes = [3321603, 3308091, 1841667, 1841475, 1828611, 1822659, 1816707, 1816515, 1810755, 1810563, 1810563, 1810371,
+         1804611, 1804419, 1798467, 1798275, 1792515, 1792323, 622083]
+bins = D.balance_files(sizes, world)
+assert sorted(i for b in bins for i in b) == list(range(len(sizes)))
+loads = [sum(sizes[i] for i in b) for b in bins]
+assert max(loads) - min(loads) <= max(sizes)            # greedy by size: no rank more than one file ahead
+most = max(len(b) for b in bins)
+tiles = torch.zeros((most, H, W, 4), dtype=torch.uint8)
+ids = torch.full((most,), -1, dtype=torch.int64)
+for i, fi in enumerate(bins[rank]):
+    tiles[i] = tile_of(100 + fi)
+    ids[i] = fi
+got = D.gather_tiles(tiles, dst=0)
+got_ids = [torch.empty_like(ids) for _ in range(world)] if rank == 0 else None
+dist.gather(ids, got_ids, dst=0)
+if rank == 0:
+    seen = {{}}
+    for r in range(world):
+        assert [int(x) for x in got_ids[r] if x >= 0] == bins[r]
+        for i, fi in enumerate(bins[r]):
+            assert fi not in seen
+            seen[fi] = got[r][i]
+    assert sorted(seen) == list(range(len(sizes)))
+    assert all(torch.equal(seen[fi], tile_of(100 + fi)) for fi in seen)
+    open({str(tmp_path / "ok8")!r}, "w").write("ok")
+dist.destroy_process_group()
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:                              # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "ok8").exists()
+
+
+def test_bench_refuses_a_world_that_is_not_the_one_asked_for():
+    """bench.py --gpus N inside a launcher that started another number of ranks prints no line and fails, before it
+    touches a GPU: a line over fewer GPUs than asked for would be read as the N-GPU result."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-frames", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 3 and r.stdout.strip() == "" and "--gpus 2" in r.stderr
+
+
 def test_heatmap_reader_cleaning_rules(tmp_path):
     """read_main_data's cleaning (excel_heatmap_v3.py:139-182), host-only: rows with a bad RSS cell go; beams outside
     0..63 go; FLAG filters only when asked; a beam column with an empty or non-numeric cell turns float and then fails

@@ -1609,6 +1609,37 @@ def test_float_rss_pivot_follows_pandas(ops, mapping):
         assert np.array_equal(c, co) and np.array_equal(s.view(np.uint64), so.view(np.uint64)), trial
 
 
+def test_float_rss_pivot_of_a_million_rows(ops, mapping):
+    """A 10^6-row table of two-decimal dBm readings: the device brings each cell's rows together in row order (stable
+    sort by cell) and adds them up with pandas' compensated recurrence; sums, counts and means are the oracle's bit for
+    bit.  Work grows with rows + cells, so this takes a fraction of a second; also a skewed table (one cell holds a
+    twentieth of the rows) and a table in which no row has a cell."""
+    import time
+    rng = np.random.default_rng(29)
+    b2a, angles = ops.axis_from_mapping(mapping)
+    n = 1_000_000
+    for skew in (False, True):
+        ue, bs = rng.integers(0, 64, n), rng.integers(0, 64, n)
+        if skew:
+            hot = rng.random(n) < 0.05
+            ue[hot], bs[hot] = 17, 42
+        rss = np.round(rng.normal(-72.0, 9.0, n), 2)
+        rss[rng.random(n) < 0.001] = np.nan
+        ops.pivot_mean_f64(ue[:1000], bs[:1000], rss[:1000], b2a, len(angles))          # first call: workspace
+        t0 = time.perf_counter()
+        s, c, m = ops.pivot_mean_f64(ue, bs, rss, b2a, len(angles))
+        dt = time.perf_counter() - t0
+        mo, _aod, _aoa, so, co = O.pivot_mean_float_lockstep(ue, bs, rss, mapping)
+        assert np.array_equal(c, co) and np.array_equal(s.view(np.uint64), so.view(np.uint64)), skew
+        rows, cols = np.flatnonzero(c.sum(1) > 0), np.flatnonzero(c.sum(0) > 0)
+        got = m[np.ix_(rows, cols)]
+        assert np.array_equal(got.view(np.uint64), mo.view(np.uint64)), skew
+        print(f"float pivot of {n} rows (skewed: {skew}): {dt * 1e3:.1f} ms with the copies to and from the device")
+        assert dt < 5.0
+    s, c, m = ops.pivot_mean_f64(np.full(5000, 70), np.full(5000, 3), np.ones(5000), b2a, len(angles))
+    assert int(c.sum()) == 0 and np.isnan(m).all()
+
+
 def test_batched_call_with_counts_left_to_the_workspace(mapping, lut):
     """tile_cnt_dev, kept_cnt_dev and the cell / map buffers are optional: left NULL they live in the ctx workspace.
     Counters, matrices and tiles are those of a run with caller-owned buffers (the per-block kept counts must not share

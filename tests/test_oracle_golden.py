@@ -284,6 +284,21 @@ def test_oracle_float_pivot_against_the_reference_fixture():
         want = z[name + "_matrix"]
         assert np.array_equal(np.isnan(mat), np.isnan(want)), name
         assert np.array_equal(mat.view(np.uint64)[~np.isnan(mat)], want.view(np.uint64)[~np.isnan(want)]), name
+        # the lock-step form used for large tables: same bits, sums and counts included
+        mat2, aod2, aoa2, s2, c2 = O.pivot_mean_float_lockstep(z[name + "_ue"], z[name + "_bs"], z[name + "_rss"], mapping)
+        assert aod2 == aod and aoa2 == aoa and np.array_equal(c2, c), name
+        assert np.array_equal(s2.view(np.uint64), s.view(np.uint64)) and np.array_equal(mat2.view(np.uint64), mat.view(np.uint64)), name
+    rng = np.random.default_rng(11)
+    mp = {i: float(i // 2) for i in range(0, 64) if i % 7}               # duplicate angles and unmapped beams
+    for trial in range(4):
+        n = int(rng.integers(0, 20000))
+        ue, bs = rng.integers(-2, 66, n), rng.integers(-2, 66, n)
+        rss = rng.normal(-70, 20, n) * rng.choice([1.0, 1e-5, 1e7, 1e300], n)
+        rss[rng.random(n) < 0.01] = np.nan
+        rss[rng.random(n) < 0.002] = np.inf
+        a, b = O.pivot_mean_float(ue, bs, rss, mp), O.pivot_mean_float_lockstep(ue, bs, rss, mp)
+        assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[4], b[4]), trial
+        assert np.array_equal(a[3].view(np.uint64), b[3].view(np.uint64)), trial
     # whole numbers: the compensated sum is the exact integer sum
     rows = np.load(os.path.join(GOLDEN, "log0.npz"))["kept"]
     a = O.pivot_mean_float(rows[:, 0], rows[:, 1], rows[:, 2].astype(np.float64), mapping)

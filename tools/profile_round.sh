@@ -6,7 +6,7 @@ root=$(pwd)
 mkdir -p "$root/gpurun_out/prof"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 "$root/bench.py" --cpu-frames 0 --steps 30 --warmup 2 --no-other-configs > "$root/gpurun_out/prof/kt_bench.json" 2> "$root/gpurun_out/prof/kt.log"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 "$root/bench.py" --cpu-frames 0 --steps 30 --warmup 2 --no-other-configs --no-pcie-fed > "$root/gpurun_out/prof/kt_bench.json" 2> "$root/gpurun_out/prof/kt.log"
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) "$root/gpurun_out/prof/kernel_stats.csv"
 cd "$root"
 tools/pmc_pass.sh fetch "FETCH_SIZE"
