@@ -340,6 +340,11 @@ int slam_read_probe_dev(slam_ctx *ctx, void *scratch_dev, const void *src_dev, s
  * total milliseconds from HIP events recorded on the ctx's stream around each launch (only when
  * enabled; off by default).  names_out receives up to cap entries of 32 chars. */
 int slam_timing_enable(slam_ctx *ctx, int on);
+/* Time only the kernels named in the comma-separated list (names as slam_timing_read reports them, e.g.
+ * "frame_onepass,frame_fused"); NULL or "": every kernel.  Two events per timed launch cost a pipeline of a few dozen
+ * launches per batch about 4 % of its rate, so a throughput run times its dominant kernel only.  No counterpart in the
+ * reference, which times nothing. */
+int slam_timing_select(slam_ctx *ctx, const char *names);
 int slam_timing_reset(slam_ctx *ctx);
 int slam_timing_read(slam_ctx *ctx, char *names_out, uint32_t *launches_out, float *ms_out, int cap);
 

@@ -220,6 +220,7 @@ static int get_kernel(slam_ctx *ctx, double sigma, double **kern, int *ks)
 // ---- timing ----------------------------------------------------------------------------------------------
 int slam_timer_begin(slam_ctx *ctx, const char *name)
 {
+    if (!ctx->timing_only.empty() && ctx->timing_only.find("," + std::string(name) + ",") == std::string::npos) return -1;
     int slot = -1;
     for (size_t i = 0; i < ctx->timers.size(); i++)
         if (!strncmp(ctx->timers[i].name, name, 31)) { slot = (int)i; break; }
@@ -267,6 +268,13 @@ extern "C" int slam_timing_enable(slam_ctx *ctx, int on)
     if (!ctx) return SLAM_E_INVALID;
     if (!on) timers_collect(ctx);
     ctx->timing = on != 0;
+    return SLAM_OK;
+}
+
+extern "C" int slam_timing_select(slam_ctx *ctx, const char *names)
+{
+    if (!ctx) return SLAM_E_INVALID;
+    ctx->timing_only = names && names[0] ? "," + std::string(names) + "," : std::string();
     return SLAM_OK;
 }
 

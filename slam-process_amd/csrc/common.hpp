@@ -42,6 +42,7 @@ struct slam_ctx {
     int force_two_pass = 0;
     // optional per-kernel timing
     bool timing = false;
+    std::string timing_only;    // "," + names + ",": only these kernels are timed (slam_timing_select); empty: all
     std::vector<slam_timer_slot> timers;
     struct pending_ev { int slot; hipEvent_t a, b; };
     std::vector<pending_ev> pending;

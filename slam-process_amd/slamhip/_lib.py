@@ -44,7 +44,7 @@ EXPORTS = [
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean", "slam_pivot_mean_f64",
     "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_kept_blocks", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
-    "slam_timing_enable", "slam_timing_reset", "slam_timing_read",
+    "slam_timing_enable", "slam_timing_select", "slam_timing_reset", "slam_timing_read",
 ]
 
 
@@ -144,6 +144,7 @@ def load() -> C.CDLL:
         lib.slam_kept_blocks.argtypes = [u32, u32, u32]
         lib.slam_kept_blocks.restype = u32
         lib.slam_timing_enable.argtypes = [vp, C.c_int]
+        lib.slam_timing_select.argtypes = [vp, C.c_char_p]
         lib.slam_timing_reset.argtypes = [vp]
         lib.slam_timing_read.argtypes = [vp, vp, vp, vp, C.c_int]
         for name in EXPORTS:
@@ -203,6 +204,10 @@ class Context:
     # -- timing ------------------------------------------------------------------------------
     def timing(self, on: bool) -> None:
         self.check(self.lib.slam_timing_enable(self.h, 1 if on else 0))
+
+    def timing_select(self, names=None) -> None:
+        """Time only these kernels (iterable of names as timing_read reports them); None: every kernel."""
+        self.check(self.lib.slam_timing_select(self.h, ",".join(names).encode() if names else None))
 
     def timing_reset(self) -> None:
         self.check(self.lib.slam_timing_reset(self.h))
