@@ -46,7 +46,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--frames-per-step", type=int, default=800,
+    p.add_argument("--frames-per-step", type=int, default=1600,
                    help="frames per batch (one slam_process_frames_dev call); larger batches amortise launch tails")
     p.add_argument("--beams", type=int, default=256, help="rows (UE sweeps) per frame")
     p.add_argument("--samples", type=int, default=4096, help="records per row")

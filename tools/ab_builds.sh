@@ -6,7 +6,7 @@
 set -e
 other=${1:-$PWD/slam-process_amd/slamhip/libslamhip_new.so}
 for lib in "" "$other"; do
-  for shape in "--beams 1024 --samples 8192 --frames-per-step 100 --distinct-frames 100 --upscale 4" "--beams 256 --samples 16384 --frames-per-step 200 --distinct-frames 200" ""; do
+  for shape in "--beams 1024 --samples 8192 --frames-per-step 100 --distinct-frames 100 --upscale 4" "--beams 256 --samples 16384 --frames-per-step 200 --distinct-frames 200" "--frames-per-step 800"; do
     SLAMHIP_LIB=$lib timeout -k 10 200 python bench.py $shape --cpu-frames 0 --no-other-configs --no-pcie-fed --steps 10 --warmup 2 | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])

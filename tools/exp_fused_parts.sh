@@ -5,7 +5,7 @@
 set -e
 run() {
   echo "start $3" >&2
-  SLAMHIP_LIB=$1 timeout -k 10 ${EXP_TIMEOUT:-100} python bench.py --fused $2 --cpu-frames 0 --no-other-configs --no-pcie-fed --steps 10 --warmup 2 2>/dev/null | python -c "
+  SLAMHIP_LIB=$1 timeout -k 10 ${EXP_TIMEOUT:-100} python bench.py --fused $2 --cpu-frames 0 --no-other-configs --no-pcie-fed --steps 10 --warmup 2 --frames-per-step 800 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=j['kernels']

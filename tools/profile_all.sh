@@ -29,10 +29,10 @@ pass() {   # pass <name> <rocprofv3 options...> -- <bench args...>
 
 SHORT="--steps 2 --warmup 1 --cpu-frames 0 --no-kernel-timing --no-other-configs --no-pcie-fed"
 pass default --kernel-trace --stats -- --no-other-configs --no-pcie-fed
-pass fetch --pmc FETCH_SIZE -- $SHORT --distinct-frames 800
-pass write --pmc WRITE_SIZE -- $SHORT --distinct-frames 800
+pass fetch --pmc FETCH_SIZE -- $SHORT --frames-per-step 800 --distinct-frames 800
+pass write --pmc WRITE_SIZE -- $SHORT --frames-per-step 800 --distinct-frames 800
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS"
-pass sq_256x4096 --pmc $SQ -- $SHORT --distinct-frames 800
+pass sq_256x4096 --pmc $SQ -- $SHORT --frames-per-step 800 --distinct-frames 800
 pass sq_256x16384 --pmc $SQ -- $SHORT --beams 256 --samples 16384 --frames-per-step 200 --distinct-frames 200
 pass sq_1024x8192_up4 --pmc $SQ -- $SHORT --beams 1024 --samples 8192 --frames-per-step 100 --distinct-frames 100 --upscale 4
 pass kt_256x16384 --kernel-trace --stats -- --cpu-frames 0 --no-other-configs --no-pcie-fed --steps 5 --warmup 1 --beams 256 --samples 16384 --frames-per-step 200 --distinct-frames 200
