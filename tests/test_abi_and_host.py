@@ -77,7 +77,7 @@ def test_kernel_resources():
         by_lds = (160 * 1024 // k["lds"]) * (threads // 64) // 4 if k["lds"] else 8
         return min(k["waves"], by_lds, 8)
 
-    need = {"k_frame_onepass<0>": 4, "k_frame_onepass<1>": 4,
+    need = {"k_frame_onepass<0>": 4, "k_frame_onepass<1>": 4, "k_frame_fused<0>": 4, "k_frame_fused<1>": 4,
             "k_rows_finish<unsigned char, unsigned int, 0, 3>": 6, "k_rows_finish<unsigned char, unsigned int, 1, 3>": 6,
             "k_rows_finish<unsigned char, unsigned int, 2, 3>": 4, "k_pivot<unsigned char, unsigned int>": 4,
             "k_raster": 8, "k_bl_sort_small": 6}
