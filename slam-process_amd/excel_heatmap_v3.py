@@ -260,7 +260,11 @@ def _edges(vals: List[float]) -> np.ndarray:
 def _lut_of(colormap: str) -> np.ndarray:
     """256 x 3 bytes of a matplotlib colormap as the Agg renderer writes them (rounded): entry i is the colour of the
     normalised value i / 256, which for the usual 256-entry maps is the map's own entry i and for a map of fewer
-    colours (tab10, Set1, ...) the colour that value falls on."""
+    colours (tab10, Set1, ...) the colour that value falls on.  The device looks up entry floor(norm * 256), so for a
+    map whose number of colours N does not divide 256 a cell whose normalised value lies in [k / N, ceil(256 k / N) / 256)
+    -- a band of less than 1 / 256 of the range above each colour boundary -- takes the colour below the boundary where
+    matplotlib takes the one above: exact for maps of 256, 128, 64 ... colours (viridis, the default, among them), not
+    pinned inside those bands for the others."""
     cmap = plt.get_cmap(colormap)
     return np.rint(np.asarray(cmap(np.arange(256) / 256.0))[:, :3] * 255).astype(np.uint8)
 
