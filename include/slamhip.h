@@ -156,6 +156,22 @@ int slam_render(slam_ctx *ctx, const double *mat, int h, int w,
                 const uint8_t *lut256x3, uint8_t *cells_rgba, uint8_t *tile_rgba, int W, int H,
                 double *vmin_vmax_out);
 
+/* ---- next to the path: the dictionary correlation of the reference's path estimators -------------------
+ * out[f] = Phi_RX^T . M[f] . Phi_TX in float64, for n_frames matrices at once: the line
+ * `correlation = self.Phi_RX.T @ res_mat @ self.Phi_TX` that opens every round of LoSEstimator.estimate_los_path
+ * (heatmap_gemini_v4.py:207-209) and NLoSEstimator.estimate_nlos_paths (:304; the same line in heatmap_gemini_v1 .. v3).
+ * Row-major: phi_rx [n_ue x ga] and phi_tx [n_bs x gd] as construct_dictionary builds them (:182-198, :283-296; one row
+ * per beam, one column per point of the search grid), m [n_frames x n_ue x n_bs] with UE rows and BS columns as
+ * BeamDataProcessor.pivot_data leaves the matrix (:117-150), out [n_frames x ga x gd].  n_ue, n_bs <= 64 (beam ids are
+ * 6 bit), any ga, gd.  Sums run on the f64 matrix cores in another order than NumPy's BLAS: results agree to about
+ * 1e-13 of the largest element, not bit for bit.  The estimators' other steps (arg-max, NNLS, masks, clustering, plots)
+ * are not part of this library. */
+int slam_dict_correlate(slam_ctx *ctx, const double *phi_rx, int n_ue, int ga, const double *phi_tx, int n_bs, int gd,
+                        const double *m, uint32_t n_frames, double *out);
+/* the same on device pointers, asynchronous on the ctx's stream */
+int slam_dict_correlate_dev(slam_ctx *ctx, const double *phi_rx_dev, int n_ue, int ga, const double *phi_tx_dev, int n_bs,
+                            int gd, const double *m_dev, uint32_t n_frames, double *out_dev);
+
 /* ---- batched, device-resident pipeline (the benchmark path) ----------------------------------------
  * F frames of hex text resident in device memory -> per frame: decoded records, corrected rows,
  * mean matrix, blurred matrix, RGBA tile.  Everything stays on the device; nothing synchronises.

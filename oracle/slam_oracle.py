@@ -580,3 +580,58 @@ def render(matrix, aod_list, aoa_list, lut, use_log=False, vmin=None, vmax=None,
     cells = colour_cells(nrm, lut)
     tile = raster(cells, edges(aoa_list), edges(aod_list), W, H)
     return dict(blurred=mat, norm=nrm, vmin=lo, vmax=hi, cells=cells, tile=tile)
+
+
+# ---------------------------------------------------------------------------
+# beyond the three scripts: the dictionary correlation of the path estimators (heatmap_gemini_v4.py)
+# ---------------------------------------------------------------------------
+def gaussian_beam(x, center, width: float) -> np.ndarray:
+    """LoSEstimator._gaussian_beam (heatmap_gemini_v4.py:175-180): exp(-(x - c)^2 / (2 sigma^2)), sigma = FWHM / 2.355."""
+    sigma = width / 2.355
+    return np.exp(-((np.asarray(x, np.float64) - np.asarray(center, np.float64)) ** 2) / (2 * sigma ** 2))
+
+
+def los_dictionary(ue_angles, bs_angles, grid_res: float = 0.1, beam_width: float = 1.4):
+    """LoSEstimator.construct_dictionary (:182-198): grids from the smallest to (short of) the largest angle in steps
+    of grid_res; Phi_RX [n_ue, len(aoa_grid)], Phi_TX [n_bs, len(aod_grid)].  Returns (aoa_grid, aod_grid, Phi_RX, Phi_TX)."""
+    ue, bs = np.asarray(ue_angles, np.float64), np.asarray(bs_angles, np.float64)
+    aoa = np.arange(np.min(ue), np.max(ue), grid_res)
+    aod = np.arange(np.min(bs), np.max(bs), grid_res)
+    return aoa, aod, gaussian_beam(ue[:, None], aoa[None, :], beam_width), gaussian_beam(bs[:, None], aod[None, :], beam_width)
+
+
+def nlos_dictionary(ue_angles, bs_angles, grid_res: float = 0.1, beam_width: float = 1.4):
+    """NLoSEstimator.construct_dictionary (:283-296) with its own _gaussian_beam (:271-281): grids up to and including
+    the largest angle (arange(min, max + grid_res, grid_res)); Phi[i, j] = beam centred on angle i seen at grid point j."""
+    ue, bs = np.asarray(ue_angles, np.float64), np.asarray(bs_angles, np.float64)
+    sigma = beam_width / 2.355
+    aoa = np.arange(np.min(ue), np.max(ue) + grid_res, grid_res)
+    aod = np.arange(np.min(bs), np.max(bs) + grid_res, grid_res)
+
+    def beam(query, centers):
+        q, c = np.meshgrid(query, centers)
+        return np.exp(-((q - c) ** 2) / (2 * sigma ** 2))
+    return aoa, aod, beam(aoa, ue), beam(aod, bs)
+
+
+def dict_correlation(phi_rx, m, phi_tx) -> np.ndarray:
+    """correlation = Phi_RX.T @ res_mat @ Phi_TX (heatmap_gemini_v4.py:209, :304), float64.  m [n_ue, n_bs] or a stack
+    [F, n_ue, n_bs]."""
+    a, b = np.asarray(phi_rx, np.float64), np.asarray(phi_tx, np.float64)
+    return a.T @ np.asarray(m, np.float64) @ b
+
+
+def dict_correlation_loops(phi_rx, m, phi_tx) -> np.ndarray:
+    """The same sums written out element by element in index order (tiny cases only)."""
+    a, b, mm = np.asarray(phi_rx, np.float64), np.asarray(phi_tx, np.float64), np.asarray(m, np.float64)
+    out = np.zeros((a.shape[1], b.shape[1]))
+    for i in range(a.shape[1]):
+        for j in range(b.shape[1]):
+            acc = 0.0
+            for v in range(b.shape[0]):
+                t = 0.0
+                for u in range(a.shape[0]):
+                    t += a[u, i] * mm[u, v]
+                acc += t * b[v, j]
+            out[i, j] = acc
+    return out

@@ -814,6 +814,51 @@ extern "C" int slam_render(slam_ctx *ctx, const double *mat, int h, int w, const
 }
 
 // ------------------------------------------------------------------------------------------------------
+// dictionary correlation of the path estimators
+// ------------------------------------------------------------------------------------------------------
+static int check_dict(slam_ctx *ctx, const void *phi_rx, int n_ue, int ga, const void *phi_tx, int n_bs, int gd, const void *m,
+                      uint32_t n_frames, const void *out)
+{
+    if (n_ue < 1 || n_ue > 64 || n_bs < 1 || n_bs > 64)
+        return slam_fail(ctx, SLAM_E_RANGE, "slam_dict_correlate: %d x %d beams, at most 64 a side", n_ue, n_bs);
+    if (ga < 1 || gd < 1 || ga > 65535 * 64)
+        return slam_fail(ctx, SLAM_E_RANGE, "slam_dict_correlate: search grid of %d x %d points", ga, gd);
+    if (n_frames > 65535u) return slam_fail(ctx, SLAM_E_RANGE, "slam_dict_correlate: at most 65535 matrices per call, got %u", n_frames);
+    if (!phi_rx || !phi_tx || (n_frames && (!m || !out))) return slam_fail(ctx, SLAM_E_INVALID, "slam_dict_correlate: NULL pointer");
+    return SLAM_OK;
+}
+
+extern "C" int slam_dict_correlate_dev(slam_ctx *ctx, const double *phi_rx_dev, int n_ue, int ga, const double *phi_tx_dev, int n_bs,
+                                       int gd, const double *m_dev, uint32_t n_frames, double *out_dev)
+{
+    REQUIRE_CTX(ctx);
+    SLAM_TRY(check_dict(ctx, phi_rx_dev, n_ue, ga, phi_tx_dev, n_bs, gd, m_dev, n_frames, out_dev));
+    return dict_correlate(ctx, phi_rx_dev, n_ue, ga, phi_tx_dev, n_bs, gd, m_dev, n_frames, out_dev);
+}
+
+extern "C" int slam_dict_correlate(slam_ctx *ctx, const double *phi_rx, int n_ue, int ga, const double *phi_tx, int n_bs, int gd,
+                                   const double *m, uint32_t n_frames, double *out)
+{
+    REQUIRE_CTX(ctx);
+    SLAM_TRY(check_dict(ctx, phi_rx, n_ue, ga, phi_tx, n_bs, gd, m, n_frames, out));
+    if (n_frames == 0) return SLAM_OK;
+    ws_plan p;
+    const size_t ba = (size_t)n_ue * ga * 8, bb = (size_t)n_bs * gd * 8, bm = (size_t)n_frames * n_ue * n_bs * 8,
+                 bo = (size_t)n_frames * ga * gd * 8;
+    const size_t oa = p.add(ba), ob = p.add(bb), om = p.add(bm), oo = p.add(bo);
+    SLAM_TRY(slam_ws_reserve(ctx, p.total));
+    uint8_t *b = ctx->ws;
+    SLAM_TRY(h2d(ctx, b + oa, phi_rx, ba));
+    SLAM_TRY(h2d(ctx, b + ob, phi_tx, bb));
+    SLAM_TRY(h2d(ctx, b + om, m, bm));
+    SLAM_TRY(dict_correlate(ctx, (const double *)(b + oa), n_ue, ga, (const double *)(b + ob), n_bs, gd, (const double *)(b + om),
+                            n_frames, (double *)(b + oo)));
+    SLAM_TRY(d2h(ctx, out, b + oo, bo));
+    SLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // batched device-resident pipeline
 // ------------------------------------------------------------------------------------------------------
 struct batch_plan {

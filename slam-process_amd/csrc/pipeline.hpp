@@ -249,6 +249,12 @@ int raster_only(slam_ctx *ctx, const uint8_t *cells, const int16_t *colmap, cons
                 uint32_t F, int W, int H, uint8_t *tile, uint32_t cell_stride);
 int slam_gaussian_kernel_host(double sigma, std::vector<double> &k);
 
+// ---- dictionary correlation (k_dict.hip) -----------------------------------------------------------
+// out[f] = phi_rx^T . m[f] . phi_tx, f64 row-major device arrays: phi_rx [n_ue x ga], phi_tx [n_bs x gd],
+// m [n_frames x n_ue x n_bs], out [n_frames x ga x gd]; n_ue, n_bs <= 64.
+int dict_correlate(slam_ctx *ctx, const double *phi_rx, int n_ue, int ga, const double *phi_tx, int n_bs, int gd,
+                   const double *m, uint32_t n_frames, double *out);
+
 // ---- general tokenizer ---------------------------------------------------------------------------
 // text -> bytes with the reference's exact token rules; n_out_dev receives the count; ws holds
 // tokenize_ws_bytes(n_text) bytes of scratch.

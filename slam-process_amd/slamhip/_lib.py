@@ -42,7 +42,7 @@ def cells_per_frame(n_axis: int) -> int:
 EXPORTS = [
     "slam_ctx_create", "slam_ctx_destroy", "slam_set_stream", "slam_use_own_stream", "slam_sync", "slam_last_error", "slam_version", "slam_abi_revision", "slam_set_fused", "slam_get_fused",
     "slam_hex_unpack", "slam_token_rejects", "slam_parse_records", "slam_parse_rejects", "slam_parse_text", "slam_correct", "slam_pivot_mean", "slam_pivot_mean_f64",
-    "slam_blur_nan", "slam_render", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
+    "slam_blur_nan", "slam_render", "slam_dict_correlate", "slam_dict_correlate_dev", "slam_process_frames_dev", "slam_process_frames_noalloc_dev", "slam_raster_dev", "slam_reserve_workspace", "slam_pin_workspace", "slam_batch_sizeof",
     "slam_row_tiles", "slam_kept_blocks", "slam_cells_per_frame", "slam_synth_text_len", "slam_synth_frames_dev", "slam_copy_probe_dev", "slam_read_probe_dev",
     "slam_timing_enable", "slam_timing_select", "slam_timing_reset", "slam_timing_read",
 ]
@@ -139,6 +139,8 @@ def load() -> C.CDLL:
         lib.slam_synth_frames_dev.argtypes = [vp, vp, u64, u32, u32, u32, u32, u64]
         lib.slam_copy_probe_dev.argtypes = [vp, vp, vp, sz]
         lib.slam_read_probe_dev.argtypes = [vp, vp, vp, sz, C.c_int]
+        lib.slam_dict_correlate.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, u32, vp]
+        lib.slam_dict_correlate_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, u32, vp]
         lib.slam_row_tiles.argtypes = [u32, u32]
         lib.slam_row_tiles.restype = u32
         lib.slam_kept_blocks.argtypes = [u32, u32, u32]

@@ -227,3 +227,48 @@ def render(mat: np.ndarray, aod, aoa, lut: np.ndarray, use_log: bool = False, vm
                               nan if vmin is None else float(vmin), nan if vmax is None else float(vmax),
                               ptr(l), ptr(cells), ptr(tile), int(W), int(H), ptr(vv)))
     return cells, tile, float(vv[0]), float(vv[1])
+
+
+# ---- next to the path: the dictionary correlation of the reference's path estimators ---------------------------
+def los_dictionary(ue_angles, bs_angles, grid_res: float = 0.1, beam_width: float = 1.4):
+    """LoSEstimator.construct_dictionary (heatmap_gemini_v4.py:182-198) with its _gaussian_beam (:175-180): search grids
+    from the smallest to short of the largest angle, Gaussian beams of FWHM beam_width.  Host-side set-up, done once per
+    angle set.  Returns (aoa_grid, aod_grid, Phi_RX [n_ue, len(aoa_grid)], Phi_TX [n_bs, len(aod_grid)])."""
+    ue, bs = np.asarray(ue_angles, np.float64), np.asarray(bs_angles, np.float64)
+    sigma = beam_width / 2.355
+    aoa = np.arange(np.min(ue), np.max(ue), grid_res)
+    aod = np.arange(np.min(bs), np.max(bs), grid_res)
+    beam = lambda x, c: np.exp(-((x - c) ** 2) / (2 * sigma ** 2))          # noqa: E731
+    return aoa, aod, beam(ue[:, None], aoa[None, :]), beam(bs[:, None], aod[None, :])
+
+
+def nlos_dictionary(ue_angles, bs_angles, grid_res: float = 0.1, beam_width: float = 1.4):
+    """NLoSEstimator.construct_dictionary (heatmap_gemini_v4.py:283-296) with its _gaussian_beam (:271-281): the grids
+    run up to and including the largest angle.  Same return as los_dictionary."""
+    ue, bs = np.asarray(ue_angles, np.float64), np.asarray(bs_angles, np.float64)
+    sigma = beam_width / 2.355
+    aoa = np.arange(np.min(ue), np.max(ue) + grid_res, grid_res)
+    aod = np.arange(np.min(bs), np.max(bs) + grid_res, grid_res)
+
+    def beam(query, centers):
+        q, c = np.meshgrid(query, centers)
+        return np.exp(-((q - c) ** 2) / (2 * sigma ** 2))
+    return aoa, aod, beam(aoa, ue), beam(aod, bs)
+
+
+def dict_correlate(phi_rx: np.ndarray, m: np.ndarray, phi_tx: np.ndarray, device: int = 0) -> np.ndarray:
+    """correlation = Phi_RX.T @ res_mat @ Phi_TX (heatmap_gemini_v4.py:209, :304) on the device, float64.
+    m [n_ue, n_bs] gives [ga, gd]; a stack m [F, n_ue, n_bs] gives [F, ga, gd]."""
+    c = _lib.ctx(device)
+    a = np.ascontiguousarray(phi_rx, dtype=np.float64)
+    b = np.ascontiguousarray(phi_tx, dtype=np.float64)
+    mm = np.ascontiguousarray(m, dtype=np.float64)
+    single = mm.ndim == 2
+    if single:
+        mm = mm[None]
+    if a.ndim != 2 or b.ndim != 2 or mm.ndim != 3 or mm.shape[1:] != (a.shape[0], b.shape[0]):
+        raise ValueError(f"shapes do not chain: Phi_RX {a.shape}, matrix {mm.shape[1:]}, Phi_TX {b.shape}")
+    out = np.empty((mm.shape[0], a.shape[1], b.shape[1]), np.float64)
+    c.check(c.lib.slam_dict_correlate(c.h, ptr(a), a.shape[0], a.shape[1], ptr(b), b.shape[0], b.shape[1], ptr(mm),
+                                      mm.shape[0], ptr(out)))
+    return out[0] if single else out

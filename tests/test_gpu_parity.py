@@ -1784,3 +1784,53 @@ def test_rssi_matrix_of_a_table_with_more_angles_than_beams(whole):
         assert np.array_equal(np.isnan(mat), np.isnan(want))
         fin = ~np.isnan(want)
         assert np.array_equal(mat[fin].view(np.uint64), want[fin].view(np.uint64)), (n_aod, n_aoa)
+
+
+@pytest.mark.gpu
+def test_dictionary_correlation_on_the_matrix_cores(ops):
+    """slam_dict_correlate (f64 MFMA) against the correlations the reference's own estimator objects computed
+    (tests/golden/dict_corr.npz: `Phi_RX.T @ res_mat @ Phi_TX`, heatmap_gemini_v4.py:209 and :304) and against the oracle
+    at the reference's default grid of a tenth of a degree, for single matrices and stacks, odd shapes included.
+    Float64 sums in another order than BLAS: tolerance 1e-12 of the largest element of the result (measured: 1e-15)."""
+    z = np.load(os.path.join(GOLDEN, "dict_corr.npz"))
+    worst = 0.0
+    for name in ("capture", "random"):
+        ue, bs, m, res = z[name + "_ue_angles"], z[name + "_bs_angles"], z[name + "_matrix"], float(z[name + "_grid_res"])
+        for kind, build in (("los", ops.los_dictionary), ("nlos", ops.nlos_dictionary)):
+            aoa, aod, prx, ptx = build(ue, bs, grid_res=res, beam_width=1.4)
+            assert np.array_equal(aoa, z[f"{name}_{kind}_aoa"]) and np.array_equal(aod, z[f"{name}_{kind}_aod"])
+            if name == "capture":
+                assert np.array_equal(prx, z[f"{name}_{kind}_phi_rx"]) and np.array_equal(ptx, z[f"{name}_{kind}_phi_tx"])
+            want = z[f"{name}_{kind}_corr"]
+            got = ops.dict_correlate(prx, m, ptx)
+            err = np.abs(got - want).max() / np.abs(want).max()
+            worst = max(worst, err)
+            assert got.shape == want.shape and err <= 1e-12, (name, kind, err)
+    # the default grid (0.1 degree: 886 x 886 points for the whole table), a stack of residual-like matrices
+    rng = np.random.default_rng(5)
+    angles = z["random_ue_angles"]
+    aoa, aod, prx, ptx = ops.los_dictionary(angles, angles)
+    stack = rng.normal(0.0, 3.0e4, (5, 64, 64))
+    got = ops.dict_correlate(prx, stack, ptx)
+    want = O.dict_correlation(prx, stack, ptx)
+    assert got.shape == (5, len(aoa), len(aod))
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err <= 1e-12, err
+    worst = max(worst, err)
+    # shapes that fill no tile: 1 .. 64 beams a side, grids of any length, identity-like operands (rows and columns in place)
+    for n_ue, n_bs, ga, gd in ((1, 1, 1, 1), (3, 64, 17, 130), (64, 5, 129, 63), (37, 41, 200, 7), (64, 64, 64, 64)):
+        a, b, mm = rng.normal(size=(n_ue, ga)), rng.normal(size=(n_bs, gd)), rng.normal(size=(2, n_ue, n_bs))
+        got, want = ops.dict_correlate(a, mm, b), O.dict_correlation(a, mm, b)
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+        assert got.shape == want.shape and err <= 1e-12, ((n_ue, n_bs, ga, gd), err)
+    e = np.zeros((4, 6)); e[2, 5] = 1.0                                   # picks row 2 of the matrix into output row 5
+    t = np.zeros((3, 4)); t[1, 0] = 1.0                                   # ... and its column 1 into output column 0
+    mm = np.arange(12.0).reshape(4, 3)
+    got = ops.dict_correlate(e, mm, t)
+    want = np.zeros((6, 4)); want[5, 0] = mm[2, 1]
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        ops.dict_correlate(np.zeros((4, 6)), np.zeros((5, 3)), np.zeros((3, 4)))
+    with pytest.raises(ops._lib.SlamError):
+        ops.dict_correlate(np.zeros((65, 6)), np.zeros((65, 3)), np.zeros((3, 4)))
+    print(f"dictionary correlation: largest relative difference {worst:.2e}")

@@ -304,3 +304,24 @@ def test_oracle_float_pivot_against_the_reference_fixture():
     a = O.pivot_mean_float(rows[:, 0], rows[:, 1], rows[:, 2].astype(np.float64), mapping)
     b = O.pivot_mean(rows[:, 0], rows[:, 1], rows[:, 2], mapping)
     assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[4], b[4])
+
+
+def test_oracle_dictionary_correlation_against_the_reference_fixture():
+    """The path estimators' dictionaries and their correlation with a matrix (heatmap_gemini_v4.py:175-209, :271-304):
+    the oracle's restatement against what the reference's own LoSEstimator / NLoSEstimator objects held
+    (tests/golden/make_dict_corr.py).  Dictionaries and grids bit for bit (the same NumPy expressions); the correlation
+    to 1e-13 of its largest element (BLAS may order the sums differently from run to run), and the written-out loops
+    agree with the matrix products to the same bar."""
+    z = np.load(os.path.join(GOLDEN, "dict_corr.npz"))
+    for name in ("capture", "random"):
+        ue, bs, m, res = z[name + "_ue_angles"], z[name + "_bs_angles"], z[name + "_matrix"], float(z[name + "_grid_res"])
+        for kind, build in (("los", O.los_dictionary), ("nlos", O.nlos_dictionary)):
+            aoa, aod, prx, ptx = build(ue, bs, grid_res=res, beam_width=1.4)
+            assert np.array_equal(aoa, z[f"{name}_{kind}_aoa"]) and np.array_equal(aod, z[f"{name}_{kind}_aod"]), (name, kind)
+            if name == "capture":
+                assert np.array_equal(prx, z[f"{name}_{kind}_phi_rx"]) and np.array_equal(ptx, z[f"{name}_{kind}_phi_tx"]), kind
+            want = z[f"{name}_{kind}_corr"]
+            got = O.dict_correlation(prx, m, ptx)
+            assert got.shape == want.shape and np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (name, kind)
+    small = O.dict_correlation_loops(prx[:9, :11], m[:9, :7], ptx[:7, :5])
+    assert np.abs(small - O.dict_correlation(prx[:9, :11], m[:9, :7], ptx[:7, :5])).max() <= 1e-13 * np.abs(small).max()
