@@ -166,6 +166,58 @@ def test_full_size_frames_bit_exact():
         assert set(map(tuple, tile.reshape(-1, 4)[::97])) <= set(map(tuple, r["cells"].reshape(-1, 4)))
 
 
+def _dense_kept(pipe, st):
+    """The used entries of every frame's corrected-row blocks, concatenated in frame order, on the device:
+    (ue, bs, rss, clk) tensors.  Frames may differ in block size (their layout word says which)."""
+    import torch
+    from slamhip import _lib
+    rc, KB, dev = pipe.row_cap, pipe.kept_blocks, pipe.dev
+    out = [[], [], [], []]
+    for f in range(pipe.bt.n_frames):
+        S = _lib.kept_unit(st[f, _lib.STAT_LAYOUT])
+        nb = (int(st[f, _lib.STAT_ROW_SLOTS]) + S - 1) // S
+        cnt = pipe.kept_cnt[f * KB:f * KB + nb].to(torch.int64)
+        use = (torch.arange(S, device=dev)[None, :] < cnt[:, None]).reshape(-1)[:min(nb * S, rc)]
+        for o, a in zip(out, (pipe.k_ue, pipe.k_bs, pipe.k_rss, pipe.k_clk)):
+            o.append(a[f * rc:f * rc + len(use)][use])
+    return [torch.cat(o) for o in out]
+
+
+def test_fused_and_separate_kernels_agree_on_many_frames(_kernel_mode):
+    """64 full-size frames per batch, three batches of different frames: the corrected rows of the fused decode + correct
+    kernel (15,000 workgroups a batch, each exchanging baselines with its neighbours) against those of the separate
+    kernels, every row of every frame, compared on the device; counters equal word for word.  Size-independent check of
+    the exchange between workgroups beside the oracle comparisons of single frames."""
+    import torch
+    from slamhip import _lib, synth
+    from slamhip.pipeline import FramePipeline, synth_frames, STAGE_DECODE, STAGE_CORRECT
+    if _kernel_mode == "split":
+        pytest.skip("the test builds a pipeline of either kind itself; once is enough")
+    B, N, F = 256, 4096, 64
+    tl = synth.text_len(B, N)
+    stride = ((tl + 255) // 256) * 256
+    pipes = {m: FramePipeline(F, tl, tile_w=64, tile_h=64, fused=(m == "fused")) for m in ("split", "fused")}
+    served = 0
+    n_batches = 3 * int(os.environ.get("SLAMHIP_FUZZ_SCALE", "1"))                 # a long run: more batches of other frames
+    for batch in range(n_batches):
+        text = synth_frames(F, B, N, first_frame=500 + 97 * batch)
+        res = {}
+        for m, pipe in pipes.items():
+            pipe.set_uniform_layout(F, stride, tl)
+            pipe.run(text, stages=STAGE_DECODE | STAGE_CORRECT)
+            st = pipe.stats_host()
+            res[m] = (st, _dense_kept(pipe, st))
+        st_s, st_f = res["split"][0], res["fused"][0]
+        assert np.array_equal(st_s[:, :7], st_f[:, :7]), batch                     # bytes, strict, valid, discarded, groups, baselines, kept
+        assert int(st_s[:, _lib.STAT_KEPT].min()) > 500000
+        assert not (st_s[:, _lib.STAT_LAYOUT] & _lib.LAYOUT_KEPT_TILES).any()
+        served += int(((st_f[:, _lib.STAT_LAYOUT] & _lib.LAYOUT_KEPT_TILES) != 0).sum())
+        for name, a, b in zip(("ue", "bs", "rss", "clk"), res["split"][1], res["fused"][1]):
+            assert a.numel() == int(st_s[:, _lib.STAT_KEPT].sum()) and torch.equal(a, b), (batch, name)
+    print(f"fused against separate kernels: {n_batches} batches of {F} frames equal, {served} served by the fused kernel")
+    assert served >= n_batches * (F - 4)                                           # the kernel served (nearly) every frame
+
+
 def test_ragged_batch_of_captures_with_loose_text():
     """Captures of different lengths in one batch (the shape of 'all debugDoc logs batched'); one of them is
     free-form text, which the batched call flags and the general tokenizer then handles."""
