@@ -173,6 +173,22 @@ int main(void)
     CHECK(slam_render(ctx, allnan, 2, 2, aod, aoa, 0, NAN, NAN, lut, cells, NULL, 0, 0, lim) == SLAM_E_ALLNAN);
     CHECK(slam_render(ctx, rm, 2, 2, aod, aoa, 1, -5.0, NAN, lut, cells, NULL, 0, 0, lim) == SLAM_E_LIMITS);
 
+    /* ---- next to the path: the estimators' correlation Phi_RX^T . M . Phi_TX (heatmap_gemini_v4.py:209).  A dictionary with a
+     * single one picks a row / a column of the matrix into place; two beams with weights give the weighted sum */
+    {
+        double prx[4 * 6] = {0}, ptx[3 * 4] = {0}, mm[2 * 4 * 3], out[2 * 6 * 4];
+        prx[2 * 6 + 5] = 1.0;                      /* beam 2 answers at grid point 5 */
+        prx[0 * 6 + 1] = 0.5; prx[3 * 6 + 1] = 2.0;  /* grid point 1: half of beam 0 plus twice beam 3 */
+        ptx[1 * 4 + 0] = 1.0;                      /* BS beam 1 answers at grid point 0 */
+        ptx[2 * 4 + 3] = 3.0;
+        for (int i = 0; i < 24; i++) mm[i] = (double)(i < 12 ? i : 100 - i);
+        CHECK(slam_dict_correlate(ctx, prx, 4, 6, ptx, 3, 4, mm, 2, out) == SLAM_OK);
+        CHECK(out[5 * 4 + 0] == mm[2 * 3 + 1] && out[5 * 4 + 3] == 3.0 * mm[2 * 3 + 2] && out[5 * 4 + 1] == 0.0);
+        CHECK(out[1 * 4 + 0] == 0.5 * mm[0 * 3 + 1] + 2.0 * mm[3 * 3 + 1] && out[0] == 0.0);
+        CHECK(out[24 + 5 * 4 + 0] == mm[12 + 2 * 3 + 1]);                               /* the second matrix of the stack */
+        CHECK(slam_dict_correlate(ctx, prx, 65, 6, ptx, 3, 4, mm, 1, out) == SLAM_E_RANGE);
+    }
+
     CHECK(slam_ctx_destroy(ctx) == SLAM_OK);
     printf("tour ok: %d checks\n", checks);
     return 0;
