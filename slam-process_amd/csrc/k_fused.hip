@@ -44,12 +44,12 @@
 
 namespace {
 
-constexpr int FU_WAVES = 8;                          // waves per workgroup
+constexpr int FU_WAVES = FUSED_TILES / 2;            // waves per workgroup (two tiles each)
 constexpr int FU_TPW = FUSED_TILES / FU_WAVES;       // tiles per wave
 constexpr int FU_BLT = 16;                           // baselines listed per tile
 constexpr int FU_GST = 8;                            // group starts listed per tile
-constexpr int FU_MAXG = 8;                           // groups a workgroup corrects: the one running into it + 7 starting in it
-constexpr int FU_NBR = 256;                          // baselines taken from the neighbours, per side
+constexpr int FU_MAXG = FU_WAVES;                    // groups a workgroup corrects: the one running into it + those starting in it (one wave sorts one)
+constexpr int FU_NBR = FUSED_TILES >= 16 ? 256 : 192; // baselines taken from the neighbours, per side
 constexpr int FU_MAXM = 256;                         // baselines per group
 constexpr int FU_POOL = 1024;                        // table entries of all the workgroup's groups together (each padded alike)
 constexpr int FU_HOPS = 12;                          // workgroups walked per side
@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t poll_headers(const uint32_t *flag0, int dir,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64 * FU_WAVES) __attribute__((amdgpu_waves_per_eu(4)))
 void k_frame_fused(frame_src src, rows_out out, kept_out_t<uint8_t, uint32_t> kout, uint32_t *stats, fused_ws fw,
                    correct_params prm)
 {
@@ -714,7 +714,7 @@ int fused_launch(slam_ctx *ctx, int mode, const frame_src &src, uint32_t F, uint
     fused_ws fw = fz.fw;
     fw.fail = fw.flag + (size_t)F * fw.wg_stride;
     SLAM_TRY(slam_zero_async(ctx, fw.flag, ((size_t)F * fw.wg_stride + F) * sizeof(uint32_t)));
-    const dim3 grid(fused_ws::wgs_for(st_max), F), block(512);
+    const dim3 grid(fused_ws::wgs_for(st_max), F), block(64 * FU_WAVES);
     if (mode == SRC_TEXT3) {
         SLAM_LAUNCH(ctx, "frame_fused", (k_frame_fused<SRC_TEXT3>), grid, block, src, out, fz.kout, stats, fw, fz.prm);
     } else {

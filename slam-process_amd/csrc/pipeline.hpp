@@ -156,7 +156,10 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
 // frame are slotted per tile like the decoded rows: the rows kept among tile t's entries sit at the front of the
 // same entries of the kept arrays, slot_cnt[f*slot_stride + t] of them.  A frame the kernel cannot finish (see
 // k_fused.hip) is flagged in `fail` and corrected by the separate kernels, which `redo` gates.
-constexpr int FUSED_TILES = 16;                  // framing tiles a workgroup decodes and corrects
+#ifndef SLAM_FUSED_TILES
+#define SLAM_FUSED_TILES 16
+#endif
+constexpr int FUSED_TILES = SLAM_FUSED_TILES;    // framing tiles a workgroup decodes and corrects (tuning builds: 8 with four waves)
 constexpr int FUSED_ENTRIES = FUSED_TILES * SLOT_ROWS;
 constexpr int FUSED_PUB_WORDS = 256;             // 8-byte words a workgroup publishes: the baselines of its two border sweeps
 constexpr int FUSED_CNT_WORDS = 4;               // per workgroup: valid, discarded, groups, baselines
