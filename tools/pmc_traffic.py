@@ -1,5 +1,5 @@
 """HBM traffic per kernel from two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE) over
-`bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-kernel-timing --distinct-frames 800`.
+`bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-kernel-timing --frames-per-step 800 --distinct-frames 800`.
 
 usage: pmc_traffic.py <fetch_csv> <write_csv> <frames_per_launch> <beams> <samples> <out.json> [table up-scaling factor]
 
