@@ -253,18 +253,20 @@ __global__ __launch_bounds__(256) void k_rows_groups(rows_in_t<T8, T32> in, uint
 
 // The same bits the single-pass framing kernel leaves (tile_bits), computed from the row arrays: for every tile
 // of a frame the framing fallback decoded (all == 0: only those, and tiles the framing kernel flagged), or for
-// every tile (all == 1).  One wave per tile, one entry per lane and pass.
+// every tile (all == 1).  One wave per tile, one entry per lane and pass.  A wave looks after `span` tiles (64 where
+// few need work; fewer where every tile of the frames served does, so that the tiles spread over more waves).
 template <typename T8, typename T32>
-__global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats, const uint32_t *gate)
+__global__ __launch_bounds__(256) void k_tile_bits(rows_in_t<T8, T32> in, int all, const uint32_t *stats, const uint32_t *gate,
+                                                   uint32_t span)
 {
     const uint32_t f = blockIdx.y, lane = lane_id();
     if (gate && !gate[f]) return;
     const frame_span sp = span_of(in, f, stats);
     const uint32_t nt = sp.n / SLOT_ROWS;                           // tiles the frame spans
     // every lane looks at one tile; the wave then works through the tiles that need it, one at a time
-    const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const uint32_t tl = (blockIdx.x * 4 + (threadIdx.x >> 6)) * span + lane;
     const bool whole = all || (stats[f * SLAM_STAT_WORDS + SLAM_STAT_LAYOUT] & SLAM_LAYOUT_TWO_PASS);
-    const bool mine = tl < nt && (whole || (in.bits.nbase[(size_t)f * in.bits.stride + tl] & TILE_NEEDS_BITS));
+    const bool mine = lane < span && tl < nt && (whole || (in.bits.nbase[(size_t)f * in.bits.stride + tl] & TILE_NEEDS_BITS));
     uint64_t todo = __ballot(mine);
     const size_t fb = (size_t)f * in.row_cap;
     while (todo) {
@@ -1404,8 +1406,10 @@ int correct_rows(slam_ctx *ctx, const rows_in_t<T8, T32> &in, uint32_t F, const 
         if (out.slot_stride < rt_max) return slam_fail(ctx, SLAM_E_CAPACITY, "kept slot counts: stride too small");
         correct_ws w2 = ws;
         w2.rmask = in.bits.rmask;
-        SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), dim3((st_max + 255) / 256, F), block, in,
-                    in.bits_fresh ? 0 : 1, stats, ws.gate);
+        // all tiles of the frames served need their bits (nothing left them): four tiles a wave instead of 64
+        const uint32_t span = in.bits_fresh ? 64u : 4u;
+        SLAM_LAUNCH(ctx, "tile_bits", (k_tile_bits<T8, T32>), dim3((st_max + 4 * span - 1) / (4 * span), F), block, in,
+                    in.bits_fresh ? 0 : 1, stats, ws.gate, span);
         SLAM_LAUNCH(ctx, "tile_scan", k_tile_scan, dim3(F), dim3(1024), in.bits.nbound, in.bits.nbase, st_max, stats,
                     (int)SLAM_STAT_GROUPS, (int)SLAM_STAT_BASELINES, 0, ws.grp_row, ws.grp_bl, in.row_cap + 1,
                     (uint32_t)SLOT_ROWS, ws.gate);
